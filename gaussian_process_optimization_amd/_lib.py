@@ -1,0 +1,283 @@
+"""ctypes binding of libgphip.so (include/gphip.h).  No torch, no CPU fallback.
+
+The product path fails loudly when the HIP library is missing or no GPU is
+visible: ``load()`` raises ``RuntimeError``; nothing here (or anywhere in this
+package) imports ``oracle/``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgphip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+
+GP_KERNEL_RBF, GP_KERNEL_MATERN52 = 0, 1
+GP_ACQ_EI, GP_ACQ_LCB, GP_ACQ_MPI = 0, 1, 2
+GP_ERR_ARG, GP_ERR_HIP, GP_ERR_STATE, GP_ERR_RCCL, GP_ERR_NOT_PD_DIAG = -1, -2, -3, -4, -5
+
+# every symbol include/gphip.h declares: (name, restype, argtypes)
+_vp = ctypes.c_void_p
+SIGNATURES = [
+    ("gp_last_error", ctypes.c_char_p, []),
+    ("gp_version", ctypes.c_char_p, []),
+    ("gp_device_count", ctypes.c_int, [c_int_p]),
+    ("gp_device_info", ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, c_int_p, c_int64_p]),
+    ("gp_create", ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),
+    ("gp_destroy", ctypes.c_int, [_vp]),
+    ("gp_set_data", ctypes.c_int, [_vp, c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    ("gp_set_params", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_double]),
+    ("gp_fit", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
+    ("gp_get_alpha", ctypes.c_int, [_vp, c_double_p]),
+    ("gp_get_chol", ctypes.c_int, [_vp, c_double_p]),
+    ("gp_get_woodbury_inv", ctypes.c_int, [_vp, c_double_p]),
+    ("gp_kernel_matrix", ctypes.c_int, [_vp, c_double_p]),
+    ("gp_lml_grad", ctypes.c_int, [_vp, c_double_p, c_double_p, c_double_p]),
+    ("gp_set_candidates", ctypes.c_int, [_vp, c_double_p, ctypes.c_int64]),
+    ("gp_predict", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p]),
+    ("gp_predict_full_cov", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p]),
+    ("gp_predict_grad", ctypes.c_int, [_vp, c_double_p, c_double_p]),
+    ("gp_fmin", ctypes.c_int, [_vp, c_double_p]),
+    ("gp_acq", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                              ctypes.c_double, c_double_p]),
+    ("gp_acq_argbest", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_int, c_int64_p, c_double_p]),
+    ("gp_acq_grad", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                   ctypes.c_double, c_double_p, c_double_p]),
+    ("gp_comm_unique_id", ctypes.c_int, [ctypes.c_char_p]),
+    ("gp_comm_init", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    ("gp_comm_destroy", ctypes.c_int, [_vp]),
+    ("gp_comm_allgather_best", ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int64, c_double_p, c_int64_p]),
+    ("gp_comm_bcast_fit", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("gp_last_phases", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), c_double_p, c_double_p,
+                                      c_double_p]),
+    ("gp_profile", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("gp_gemm_stats", ctypes.c_int, [_vp, c_int64_p, c_double_p, c_double_p]),
+    ("gp_synchronize", ctypes.c_int, [_vp]),
+    ("gp_set_option", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libgphip.so and bind every declared symbol (no GPU needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libgphip.so is missing at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError here means header and library disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def load():
+    """Library handle, insisting on a visible GPU."""
+    lib = load_library()
+    n = ctypes.c_int(0)
+    rc = lib.gp_device_count(ctypes.byref(n))
+    if rc != 0 or n.value < 1:
+        raise RuntimeError("gphip: no HIP device visible (%s). The GP path runs on MI355X only; "
+                           "there is no CPU fallback." % lib.gp_last_error().decode())
+    return lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def as_f64(a, ndim=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError("expected a %d-D array, got shape %s" % (ndim, a.shape))
+    return a
+
+
+def check(lib, rc, what):
+    """Map C return codes to the exceptions the reference raises (linalg.py:62-75, bo.py:134-137)."""
+    if rc == 0:
+        return
+    msg = lib.gp_last_error().decode()
+    if rc > 0:
+        raise np.linalg.LinAlgError("not positive definite, even with jitter.")
+    if rc == GP_ERR_NOT_PD_DIAG:
+        raise np.linalg.LinAlgError("not pd: non-positive diagonal elements")
+    if rc == GP_ERR_ARG:
+        raise ValueError("%s: %s" % (what, msg))
+    raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))
+
+
+class Handle(object):
+    """Owns one gp_t (one device)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        check(self.lib, self.lib.gp_create(ctypes.byref(h), int(device)), "gp_create")
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- thin typed wrappers -------------------------------------------------
+    def set_data(self, X, Y):
+        X = as_f64(X, 2)
+        Y = as_f64(Y, 2)
+        if X.shape[0] != Y.shape[0]:
+            raise ValueError("X and Y row counts differ")
+        check(self.lib, self.lib.gp_set_data(self.h, dptr(X), dptr(Y), X.shape[0], X.shape[1], Y.shape[1]),
+              "gp_set_data")
+        self.N, self.D, self.P = X.shape[0], X.shape[1], Y.shape[1]
+
+    def set_params(self, kernel, ard, variance, lengthscale, noise):
+        ls = as_f64(np.atleast_1d(lengthscale), 1)
+        if ls.size != (self.D if ard else 1):
+            raise ValueError("lengthscale has %d entries, expected %d" % (ls.size, self.D if ard else 1))
+        check(self.lib, self.lib.gp_set_params(self.h, int(kernel), int(bool(ard)), float(variance), dptr(ls),
+                                               float(noise)), "gp_set_params")
+
+    def fit(self, maxtries=5):
+        lml, logdet, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        rc = self.lib.gp_fit(self.h, int(maxtries), ctypes.byref(lml), ctypes.byref(logdet), ctypes.byref(jit))
+        check(self.lib, rc, "gp_fit")
+        return lml.value, logdet.value, jit.value
+
+    def alpha(self):
+        out = np.empty((self.N, self.P))
+        check(self.lib, self.lib.gp_get_alpha(self.h, dptr(out)), "gp_get_alpha")
+        return out
+
+    def chol(self):
+        out = np.empty((self.N, self.N))
+        check(self.lib, self.lib.gp_get_chol(self.h, dptr(out)), "gp_get_chol")
+        return out
+
+    def woodbury_inv(self):
+        out = np.empty((self.N, self.N))
+        check(self.lib, self.lib.gp_get_woodbury_inv(self.h, dptr(out)), "gp_get_woodbury_inv")
+        return out
+
+    def kernel_matrix(self):
+        out = np.empty((self.N, self.N))
+        check(self.lib, self.lib.gp_kernel_matrix(self.h, dptr(out)), "gp_kernel_matrix")
+        return out
+
+    def lml_grad(self, nls):
+        dv, dn = ctypes.c_double(), ctypes.c_double()
+        dl = np.empty(nls)
+        check(self.lib, self.lib.gp_lml_grad(self.h, ctypes.byref(dv), dptr(dl), ctypes.byref(dn)), "gp_lml_grad")
+        return dv.value, dl, dn.value
+
+    def set_candidates(self, Xs):
+        Xs = as_f64(Xs, 2)
+        if Xs.shape[1] != self.D:
+            raise ValueError("candidates have %d columns, model has %d" % (Xs.shape[1], self.D))
+        check(self.lib, self.lib.gp_set_candidates(self.h, dptr(Xs), Xs.shape[0]), "gp_set_candidates")
+        self.M = Xs.shape[0]
+
+    def predict(self, include_noise=True):
+        mean = np.empty((self.M, self.P))
+        var = np.empty((self.M, 1))
+        check(self.lib, self.lib.gp_predict(self.h, int(bool(include_noise)), dptr(mean), dptr(var)), "gp_predict")
+        return mean, var
+
+    def predict_full_cov(self, include_noise=True):
+        mean = np.empty((self.M, self.P))
+        cov = np.empty((self.M, self.M))
+        check(self.lib, self.lib.gp_predict_full_cov(self.h, int(bool(include_noise)), dptr(mean), dptr(cov)),
+              "gp_predict_full_cov")
+        return mean, cov
+
+    def predict_grad(self):
+        dm = np.empty((self.M, self.D, self.P))
+        dv = np.empty((self.M, self.D))
+        check(self.lib, self.lib.gp_predict_grad(self.h, dptr(dm), dptr(dv)), "gp_predict_grad")
+        return dm, dv
+
+    def fmin(self):
+        v = ctypes.c_double()
+        check(self.lib, self.lib.gp_fmin(self.h, ctypes.byref(v)), "gp_fmin")
+        return v.value
+
+    def acq(self, type_, par, fmin, y_mean=0.0, y_std=1.0):
+        out = np.empty((self.M, 1))
+        check(self.lib, self.lib.gp_acq(self.h, int(type_), float(par), float(fmin), float(y_mean), float(y_std),
+                                        dptr(out)), "gp_acq")
+        return out
+
+    def acq_grad(self, type_, par, fmin, y_mean=0.0, y_std=1.0):
+        out = np.empty((self.M, 1))
+        dout = np.empty((self.M, self.D))
+        check(self.lib, self.lib.gp_acq_grad(self.h, int(type_), float(par), float(fmin), float(y_mean),
+                                             float(y_std), dptr(out), dptr(dout)), "gp_acq_grad")
+        return out, dout
+
+    def acq_argbest(self, type_, par, fmin, sense, y_mean=0.0, y_std=1.0):
+        idx, val = ctypes.c_int64(), ctypes.c_double()
+        check(self.lib, self.lib.gp_acq_argbest(self.h, int(type_), float(par), float(fmin), float(y_mean),
+                                                float(y_std), int(sense), ctypes.byref(idx), ctypes.byref(val)),
+              "gp_acq_argbest")
+        return idx.value, val.value
+
+    def phases(self):
+        cap = 16
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_double * cap)()
+        fl = (ctypes.c_double * cap)()
+        by = (ctypes.c_double * cap)()
+        n = self.lib.gp_last_phases(self.h, cap, names, ms, fl, by)
+        return [dict(name=names[i].decode(), ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(max(n, 0))]
+
+    def profile(self, on=True):
+        check(self.lib, self.lib.gp_profile(self.h, int(bool(on))), "gp_profile")
+
+    def gemm_stats(self):
+        n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        check(self.lib, self.lib.gp_gemm_stats(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)),
+              "gp_gemm_stats")
+        return dict(launches=n.value, ms=ms.value, flops=fl.value)
+
+    def synchronize(self):
+        check(self.lib, self.lib.gp_synchronize(self.h), "gp_synchronize")
+
+    def set_option(self, name, value):
+        check(self.lib, self.lib.gp_set_option(self.h, name.encode(), int(value)), "gp_set_option")
+
+    # -- RCCL ------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        check(self.lib, self.lib.gp_comm_unique_id(buf), "gp_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, uid, rank, nranks):
+        check(self.lib, self.lib.gp_comm_init(self.h, uid, int(rank), int(nranks)), "gp_comm_init")
+
+    def comm_allgather_best(self, val, idx, nranks):
+        vals = np.empty(nranks)
+        idxs = np.empty(nranks, dtype=np.int64)
+        check(self.lib, self.lib.gp_comm_allgather_best(self.h, float(val), int(idx), dptr(vals),
+                                                        idxs.ctypes.data_as(c_int64_p)), "gp_comm_allgather_best")
+        return vals, idxs
+
+    def comm_bcast_fit(self, root=0):
+        check(self.lib, self.lib.gp_comm_bcast_fit(self.h, int(root)), "gp_comm_bcast_fit")

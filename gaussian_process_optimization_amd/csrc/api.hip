@@ -1,0 +1,762 @@
+// C-ABI of libgphip.so and the host-side orchestration of the blocked algorithms.
+// See include/gphip.h for the contract (reference file:line per entry point).
+#include "gphip_internal.h"
+#include "../../include/gphip.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(GP_ERR_HIP, "%s -> %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define NCCLCHK(x)                                                                                   \
+    do {                                                                                             \
+        ncclResult_t r_ = (x);                                                                       \
+        if (r_ != ncclSuccess) return fail(GP_ERR_RCCL, "%s -> %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+struct Phase {
+    const char *name;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+    bool used;
+};
+#define MAX_PHASES 16
+
+struct gp_ctx {
+    int device = 0;
+    hipStream_t s = nullptr;       // main stream
+    hipStream_t s_panel = nullptr; // look-ahead (panel) stream, high priority
+    // data
+    long N = 0, Npad = 0;
+    int D = 0, P = 0;
+    double *dX = nullptr, *dY = nullptr;
+    double *dA = nullptr;     // (Npad + 128) x Npad: Ky / L (lower) and, below it, the RHS rows (Y^T -> z^T)
+    double *dInvL = nullptr;  // nt tiles of 128 x 128: inverted diagonal tiles of L
+    double *dAlpha = nullptr; // P x Npad
+    double *dW = nullptr;     // P x Npad workspace
+    double *dMu = nullptr;    // (1 + TM_SPLIT) * N : training mean + partials
+    int *dInfo = nullptr;
+    double *dScal = nullptr;  // small scalars: [0] logdet, [8..8+P) sumsq / dot
+    double *dRedV = nullptr;  // 512 doubles of reduction scratch
+    long long *dRedI = nullptr;
+    long capN = 0;
+    int capP = 0;
+    // params
+    KernParams kp{};
+    int ard = 0;
+    double noise = 0.0;
+    bool have_data = false, have_params = false, fitted = false;
+    double jitter = 0.0, lml = 0.0, logdet = 0.0;
+    bool fmin_valid = false;
+    double fmin = 0.0;
+    // candidates
+    long M = 0;
+    double *dXs = nullptr;
+    long capM = 0;
+    double *dT = nullptr;  // Mc_pad x Npad
+    long capT = 0;         // elements
+    double *dMean = nullptr, *dVar = nullptr, *dAcq = nullptr;
+    long capOut = 0;
+    bool predicted = false;
+    int predicted_noise = -1;
+    // Wi
+    double *dWi = nullptr;
+    long capWi = 0;
+    bool wi_valid = false;
+    // options
+    int panel_tiles = 4;
+    int lookahead = 0;
+    long mc_max = 16384;
+    // profiling
+    Phase phases[MAX_PHASES];
+    int nphases = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> gemm_events;
+    size_t gemm_ev_used = 0;
+    long gemm_launches = 0;
+    double gemm_flops = 0.0;
+    // comm
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+void launch_add_diag(hipStream_t s, double *A, long lda, long N, double v);
+
+static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+
+// ---- phase timing -----------------------------------------------------------------------------
+static int phase_begin(gp_ctx *g, const char *name, double flops, double bytes) {
+    if (g->nphases >= MAX_PHASES) return -1;
+    Phase &p = g->phases[g->nphases];
+    p.name = name;
+    p.flops = flops;
+    p.bytes = bytes;
+    if (!p.used) {
+        hipEventCreate(&p.e0);
+        hipEventCreate(&p.e1);
+        p.used = true;
+    }
+    hipEventRecord(p.e0, g->s);
+    return g->nphases++;
+}
+static void phase_end(gp_ctx *g, int id) {
+    if (id >= 0) hipEventRecord(g->phases[id].e1, g->s);
+}
+
+// ---- GEMM wrapper with accounting ---------------------------------------------------------------
+static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const double *A, long lda, const double *B,
+                 long ldb, int b_mul, int K, TileSet ts) {
+    const long n = tileset_count(ts);
+    if (n <= 0 || K <= 0) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g->profiling) {
+        if (g->gemm_ev_used + 2 > g->gemm_events.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            g->gemm_events.push_back(a);
+            g->gemm_events.push_back(b);
+        }
+        e0 = g->gemm_events[g->gemm_ev_used++];
+        e1 = g->gemm_events[g->gemm_ev_used++];
+        hipEventRecord(e0, s);
+    }
+    launch_gemm_nt(s, mode, C, ldc, A, lda, B, ldb, b_mul, K, ts);
+    if (g->profiling) hipEventRecord(e1, s);
+    g->gemm_launches++;
+    g->gemm_flops += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n;
+}
+
+// ---- memory helpers -----------------------------------------------------------------------------
+static int dev_realloc(double **p, long *cap, long need) {
+    if (need <= *cap && *p) return 0;
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void **)p, (size_t)need * sizeof(double));
+    if (e != hipSuccess) return fail(GP_ERR_HIP, "hipMalloc(%ld doubles) -> %s", need, hipGetErrorString(e));
+    *cap = need;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *gp_last_error(void) { return g_err.c_str(); }
+const char *gp_version(void) { return "gphip 0.1 (gfx950, fp64 MFMA)"; }
+
+int gp_device_count(int *count) {
+    if (!count) return fail(GP_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(GP_ERR_HIP, "hipGetDeviceCount -> %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return 0;
+}
+
+int gp_device_info(int device, char *name, int cap, int *cus, int64_t *hbm_bytes) {
+    hipDeviceProp_t pr;
+    HIPCHK(hipGetDeviceProperties(&pr, device));
+    if (name && cap > 0) {
+        snprintf(name, cap, "%s (%s)", pr.name, pr.gcnArchName);
+    }
+    if (cus) *cus = pr.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)pr.totalGlobalMem;
+    return 0;
+}
+
+int gp_create(gp_t **out, int device) {
+    if (!out) return fail(GP_ERR_ARG, "out is NULL");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(GP_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    HIPCHK(hipSetDevice(device));
+    gp_ctx *g = new gp_ctx();
+    g->device = device;
+    for (int i = 0; i < MAX_PHASES; ++i) g->phases[i].used = false;
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIPCHK(hipStreamCreateWithPriority(&g->s, hipStreamNonBlocking, lo));
+    HIPCHK(hipStreamCreateWithPriority(&g->s_panel, hipStreamNonBlocking, hi));
+    HIPCHK(hipMalloc((void **)&g->dInfo, sizeof(int) * 4));
+    HIPCHK(hipMalloc((void **)&g->dScal, sizeof(double) * 512));
+    HIPCHK(hipMalloc((void **)&g->dRedV, sizeof(double) * 512));
+    HIPCHK(hipMalloc((void **)&g->dRedI, sizeof(long long) * 512));
+    *out = g;
+    return 0;
+}
+
+int gp_destroy(gp_t *g) {
+    if (!g) return 0;
+    hipSetDevice(g->device);
+    hipDeviceSynchronize();
+    if (g->comm) ncclCommDestroy(g->comm);
+    double *ptrs[] = {g->dX, g->dY, g->dA, g->dInvL, g->dAlpha, g->dW, g->dMu, g->dScal, g->dRedV,
+                      g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi};
+    for (double *p : ptrs)
+        if (p) hipFree(p);
+    if (g->dInfo) hipFree(g->dInfo);
+    if (g->dRedI) hipFree(g->dRedI);
+    for (int i = 0; i < MAX_PHASES; ++i)
+        if (g->phases[i].used) {
+            hipEventDestroy(g->phases[i].e0);
+            hipEventDestroy(g->phases[i].e1);
+        }
+    for (hipEvent_t e : g->gemm_events) hipEventDestroy(e);
+    if (g->s) hipStreamDestroy(g->s);
+    if (g->s_panel) hipStreamDestroy(g->s_panel);
+    delete g;
+    return 0;
+}
+
+int gp_set_option(gp_t *g, const char *name, int64_t value) {
+    if (!g || !name) return fail(GP_ERR_ARG, "null argument");
+    if (!strcmp(name, "panel_tiles")) {
+        if (value < 1 || value > 64) return fail(GP_ERR_ARG, "panel_tiles out of range");
+        g->panel_tiles = (int)value;
+    } else if (!strcmp(name, "lookahead")) {
+        g->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "mc_max")) {
+        if (value < GP_TILE) return fail(GP_ERR_ARG, "mc_max < 128");
+        g->mc_max = round_up(value, GP_TILE);
+    } else
+        return fail(GP_ERR_ARG, "unknown option %s", name);
+    return 0;
+}
+
+int gp_synchronize(gp_t *g) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipStreamSynchronize(g->s_panel));
+    HIPCHK(hipStreamSynchronize(g->s));
+    return 0;
+}
+
+int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N, int D, int P) {
+    if (!g || !X || !Y) return fail(GP_ERR_ARG, "null argument");
+    if (N < 1 || D < 1 || D > GP_MAX_D || P < 1 || P > GP_MAX_RHS)
+        return fail(GP_ERR_ARG, "bad shape N=%ld D=%d P=%d (D <= %d, P <= %d)", (long)N, D, P, GP_MAX_D, GP_MAX_RHS);
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipStreamSynchronize(g->s));
+    const long Npad = round_up(N, GP_TILE);
+    if (Npad > g->capN || P > g->capP || !g->dA) {
+        double **bufs[] = {&g->dX, &g->dY, &g->dA, &g->dInvL, &g->dAlpha, &g->dW, &g->dMu};
+        for (double **b : bufs) {
+            if (*b) hipFree(*b);
+            *b = nullptr;
+        }
+        const long capN = Npad;
+        const int capP = std::max(P, g->capP);
+        HIPCHK(hipMalloc((void **)&g->dX, sizeof(double) * capN * GP_MAX_D));
+        HIPCHK(hipMalloc((void **)&g->dY, sizeof(double) * capN * capP));
+        HIPCHK(hipMalloc((void **)&g->dA, sizeof(double) * (capN + GP_MAX_RHS) * capN));
+        HIPCHK(hipMalloc((void **)&g->dInvL, sizeof(double) * capN * GP_TILE));
+        HIPCHK(hipMalloc((void **)&g->dAlpha, sizeof(double) * capN * capP));
+        HIPCHK(hipMalloc((void **)&g->dW, sizeof(double) * capN * capP));
+        HIPCHK(hipMalloc((void **)&g->dMu, sizeof(double) * capN * 16));
+        g->capN = capN;
+        g->capP = capP;
+    }
+    g->N = N;
+    g->Npad = Npad;
+    g->D = D;
+    g->P = P;
+    HIPCHK(hipMemcpyAsync(g->dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice, g->s));
+    HIPCHK(hipMemcpyAsync(g->dY, Y, sizeof(double) * N * P, hipMemcpyHostToDevice, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    g->have_data = true;
+    g->fitted = false;
+    g->fmin_valid = false;
+    g->wi_valid = false;
+    g->predicted = false;
+    g->kp.D = D;
+    return 0;
+}
+
+int gp_set_params(gp_t *g, int kernel, int ard, double variance, const double *lengthscale, double noise) {
+    if (!g || !lengthscale) return fail(GP_ERR_ARG, "null argument");
+    if (!g->have_data) return fail(GP_ERR_STATE, "gp_set_data must precede gp_set_params");
+    if (kernel != GP_KERNEL_RBF && kernel != GP_KERNEL_MATERN52) return fail(GP_ERR_ARG, "unknown kernel %d", kernel);
+    g->kp.kernel = kernel;
+    g->kp.D = g->D;
+    g->kp.variance = variance;
+    for (int d = 0; d < g->D; ++d) g->kp.ls[d] = ard ? lengthscale[d] : lengthscale[0];
+    g->ard = ard ? 1 : 0;
+    g->noise = noise;
+    g->have_params = true;
+    g->fitted = false;
+    g->fmin_valid = false;
+    g->wi_valid = false;
+    g->predicted = false;
+    return 0;
+}
+
+// ---- blocked right-looking Cholesky (two-level: 128-column steps inside panel_tiles-wide panels) ----
+static void factor(gp_ctx *g) {
+    const long lda = g->Npad;
+    const int nt = (int)(g->Npad / GP_TILE);
+    const int R1 = nt + 1;  // row tiles incl. the RHS tile
+    const int W = g->panel_tiles;
+    double *A = g->dA;
+    hipStream_t s = g->s;
+    for (int J0 = 0; J0 < nt; J0 += W) {
+        const int J1 = std::min(J0 + W, nt);
+        for (int j = J0; j < J1; ++j) {
+            launch_potrf_tile(s, A, lda, j, g->dInvL, g->dInfo);
+            // panel solve: A[i, j] <- A[i, j] * inv(L_jj)^T for the row tiles below (and the RHS tile)
+            gemm(g, s, 0, A, lda, A + (long)j * GP_TILE, lda, g->dInvL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0,
+                 GP_TILE, TileSet{j + 1, R1, j, j + 1, 0});
+            // update of the remaining columns of this panel (K = 128)
+            if (j + 1 < J1)
+                gemm(g, s, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE,
+                     TileSet{0, R1, j + 1, J1, 1});
+        }
+        // trailing update with the whole panel (K = W * 128): the dense contraction on MFMA
+        if (J1 < nt)
+            gemm(g, s, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, (J1 - J0) * GP_TILE,
+                 TileSet{0, R1, J1, nt, 1});
+    }
+}
+
+__global__ void dot_ay_kernel(const double *alpha, long lda_, const double *Y, long N, int P, double *out) {
+    __shared__ double sh[16];
+    const int p = blockIdx.x;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < N; i += 1024) s = fma(alpha[p * lda_ + i], Y[i * P + p], s);
+    // block reduce
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        for (int i = 0; i < 16; ++i) r += sh[i];
+        out[p] = r;
+    }
+}
+
+int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_used) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit");
+    HIPCHK(hipSetDevice(g->device));
+    const long N = g->N, Npad = g->Npad, lda = g->Npad;
+    const int P = g->P;
+    const double diag_add = g->noise + 1e-8;  // exact_gaussian_inference.py:56
+    const double diag0 = g->kp.variance + diag_add;
+    g->nphases = 0;
+    g->fitted = false;
+    g->fmin_valid = false;
+    g->wi_valid = false;
+    g->predicted = false;
+
+    double jitter = 0.0;
+    int tries = 0;  // number of jittered attempts so far
+    int info = 0;
+    for (;;) {
+        int ph = phase_begin(g, "kbuild", 0.0, 8.0 * N * g->D + 8.0 * (double)N * N / 2);
+        launch_kbuild(g->s, g->dA, lda, g->dX, N, Npad, g->kp, diag_add, 0);
+        // jitchol retries factor (Ky + jitter I): the jitter lands on the assembled diagonal (linalg.py:69)
+        if (jitter != 0.0) launch_add_diag(g->s, g->dA, lda, N, jitter);
+        launch_set_rhs(g->s, g->dA, lda, g->dY, N, Npad, P);
+        phase_end(g, ph);
+        HIPCHK(hipMemsetAsync(g->dInfo, 0, sizeof(int) * 4, g->s));
+        ph = phase_begin(g, "cholesky", (double)N * N * N / 3.0, 0.0);
+        factor(g);
+        phase_end(g, ph);
+        HIPCHK(hipMemcpyAsync(&info, g->dInfo, sizeof(int), hipMemcpyDeviceToHost, g->s));
+        HIPCHK(hipStreamSynchronize(g->s));
+        if (info == 0) break;
+        // jitter ladder, GPy/GPy/util/linalg.py:62-75
+        if (!(diag0 > 0.0)) return fail(GP_ERR_NOT_PD_DIAG, "not pd: non-positive diagonal elements");
+        if (tries == 0)
+            jitter = diag0 * 1e-6;
+        else
+            jitter *= 10.0;
+        ++tries;
+        if (tries > maxtries || !std::isfinite(jitter)) {
+            g_err = "not positive definite, even with jitter.";
+            return info > 0 ? info : 1;
+        }
+        g->nphases = 0;
+    }
+    g->jitter = jitter;
+
+    int ph = phase_begin(g, "alpha_lml", 2.0 * (double)N * N * P, 8.0 * (double)N * N / 2);
+    launch_logdet(g->s, g->dA, lda, N, g->dScal);
+    launch_trsv_backward(g->s, g->dA, lda, g->dInvL, Npad, g->dA + Npad * lda, lda, P, g->dAlpha, g->dW);
+    hipLaunchKernelGGL(dot_ay_kernel, dim3(P), dim3(1024), 0, g->s, g->dAlpha, Npad, g->dY, N, P, g->dScal + 8);
+    phase_end(g, ph);
+    std::vector<double> sc(8 + P);
+    HIPCHK(hipMemcpyAsync(sc.data(), g->dScal, sizeof(double) * (8 + P), hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    double fit = 0.0;
+    for (int p = 0; p < P; ++p) fit += sc[8 + p];
+    g->logdet = sc[0];
+    const double log_2_pi = std::log(2.0 * M_PI);
+    g->lml = 0.5 * (-(double)N * P * log_2_pi - P * g->logdet - fit);  // exact_gaussian_inference.py:62
+    g->fitted = true;
+    if (lml) *lml = g->lml;
+    if (logdet) *logdet = g->logdet;
+    if (jitter_used) *jitter_used = g->jitter;
+    return 0;
+}
+
+int gp_get_alpha(gp_t *g, double *alpha) {
+    if (!g || !alpha) return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    HIPCHK(hipSetDevice(g->device));
+    std::vector<double> tmp((size_t)g->P * g->Npad);
+    HIPCHK(hipMemcpy(tmp.data(), g->dAlpha, sizeof(double) * g->P * g->Npad, hipMemcpyDeviceToHost));
+    for (long i = 0; i < g->N; ++i)
+        for (int p = 0; p < g->P; ++p) alpha[i * g->P + p] = tmp[(size_t)p * g->Npad + i];
+    return 0;
+}
+
+int gp_get_chol(gp_t *g, double *L) {
+    if (!g || !L) return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    HIPCHK(hipSetDevice(g->device));
+    const long N = g->N;
+    HIPCHK(hipMemcpy2D(L, sizeof(double) * N, g->dA, sizeof(double) * g->Npad, sizeof(double) * N, N,
+                       hipMemcpyDeviceToHost));
+    for (long i = 0; i < N; ++i)
+        for (long j = i + 1; j < N; ++j) L[i * N + j] = 0.0;
+    return 0;
+}
+
+int gp_kernel_matrix(gp_t *g, double *K) {
+    if (!g || !K) return fail(GP_ERR_ARG, "null argument");
+    if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params first");
+    HIPCHK(hipSetDevice(g->device));
+    const long N = g->N;
+    launch_kbuild(g->s, g->dA, g->Npad, g->dX, N, g->Npad, g->kp, 0.0, 1);
+    HIPCHK(hipStreamSynchronize(g->s));
+    HIPCHK(hipMemcpy2D(K, sizeof(double) * N, g->dA, sizeof(double) * g->Npad, sizeof(double) * N, N,
+                       hipMemcpyDeviceToHost));
+    g->fitted = false;  // dA was overwritten
+    g->wi_valid = false;
+    g->predicted = false;
+    return 0;
+}
+
+// ---- candidates / predict -----------------------------------------------------------------------
+int gp_set_candidates(gp_t *g, const double *Xs, int64_t M) {
+    if (!g || !Xs) return fail(GP_ERR_ARG, "null argument");
+    if (!g->have_data) return fail(GP_ERR_STATE, "gp_set_data first");
+    if (M < 1) return fail(GP_ERR_ARG, "M < 1");
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipStreamSynchronize(g->s));
+    int rc;
+    if ((rc = dev_realloc(&g->dXs, &g->capM, (long)M * g->D))) return rc;
+    HIPCHK(hipMemcpy(g->dXs, Xs, sizeof(double) * M * g->D, hipMemcpyHostToDevice));
+    g->M = M;
+    g->predicted = false;
+    return 0;
+}
+
+// candidate solve on the resident chunk: T <- T L^-T  (T = K(Xs, X), candidate-major)
+static void solve_candidates(gp_ctx *g, long mcpad) {
+    const long Npad = g->Npad, lda = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    const int mt = (int)(mcpad / GP_TILE);
+    const int W = g->panel_tiles;
+    double *T = g->dT;
+    const double *L = g->dA;
+    hipStream_t s = g->s;
+    for (int J0 = 0; J0 < nt; J0 += W) {
+        const int J1 = std::min(J0 + W, nt);
+        for (int b = J0; b < J1; ++b) {
+            gemm(g, s, 0, T, Npad, T + (long)b * GP_TILE, Npad, g->dInvL + (long)b * GP_TILE * GP_TILE, GP_TILE, 0,
+                 GP_TILE, TileSet{0, mt, b, b + 1, 0});
+            if (b + 1 < J1)
+                gemm(g, s, 1, T, Npad, T + (long)b * GP_TILE, Npad, L + (long)b * GP_TILE, lda, 1, GP_TILE,
+                     TileSet{0, mt, b + 1, J1, 0});
+        }
+        if (J1 < nt)
+            gemm(g, s, 1, T, Npad, T + (long)J0 * GP_TILE, Npad, L + (long)J0 * GP_TILE, lda, 1, (J1 - J0) * GP_TILE,
+                 TileSet{0, mt, J1, nt, 0});
+    }
+}
+
+static int run_predict(gp_ctx *g, int include_noise) {
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    HIPCHK(hipSetDevice(g->device));
+    const long M = g->M, N = g->N, Npad = g->Npad;
+    const int P = g->P;
+    int rc;
+    g->nphases = 0;
+    const long mc_max = std::min(g->mc_max, round_up(M, GP_TILE));
+    if ((rc = dev_realloc(&g->dT, &g->capT, mc_max * Npad))) return rc;
+    for (long m0 = 0; m0 < M; m0 += mc_max) {
+        const long mc = std::min(mc_max, M - m0);
+        const long mcpad = round_up(mc, GP_TILE);
+        int ph = phase_begin(g, "cross_k", 0.0, 8.0 * (double)(N + mc) * g->D + 8.0 * (double)N * mc);
+        launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, g->N, Npad, g->kp);
+        phase_end(g, ph);
+        ph = phase_begin(g, "cand_solve", (double)N * N * mc, 0.0);
+        solve_candidates(g, mcpad);
+        phase_end(g, ph);
+        ph = phase_begin(g, "reduce", 0.0, 8.0 * (double)N * mc);
+        launch_predict_reduce(g->s, g->dT, Npad, mc, N, g->dA + Npad * Npad, Npad, P, g->kp.variance,
+                              include_noise ? g->noise : 0.0, g->dMean + m0 * P, g->dVar + m0);
+        phase_end(g, ph);
+    }
+    g->predicted = true;
+    g->predicted_noise = include_noise ? 1 : 0;
+    return 0;
+}
+
+static int ensure_out(gp_ctx *g) {
+    const long need = g->M * (long)std::max(1, g->P);
+    if (g->dMean && g->dVar && g->dAcq && g->capOut >= need) return 0;
+    for (double **b : {&g->dMean, &g->dVar, &g->dAcq}) {
+        if (*b) hipFree(*b);
+        *b = nullptr;
+    }
+    HIPCHK(hipMalloc((void **)&g->dMean, sizeof(double) * need));
+    HIPCHK(hipMalloc((void **)&g->dVar, sizeof(double) * need));
+    HIPCHK(hipMalloc((void **)&g->dAcq, sizeof(double) * need));
+    g->capOut = need;
+    return 0;
+}
+
+int gp_predict(gp_t *g, int include_noise, double *mean, double *var) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = ensure_out(g))) return rc;
+    if ((rc = run_predict(g, include_noise))) return rc;
+    if (mean) HIPCHK(hipMemcpyAsync(mean, g->dMean, sizeof(double) * g->M * g->P, hipMemcpyDeviceToHost, g->s));
+    if (var) HIPCHK(hipMemcpyAsync(var, g->dVar, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    return 0;
+}
+
+int gp_fmin(gp_t *g, double *fmin) {
+    if (!g || !fmin) return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->P != 1) return fail(GP_ERR_ARG, "gp_fmin needs P == 1");
+    HIPCHK(hipSetDevice(g->device));
+    if (!g->fmin_valid) {
+        launch_train_mean(g->s, g->dX, g->N, g->kp, g->dAlpha, g->dMu);
+        launch_argbest(g->s, g->dMu, g->N, -1, g->dRedV + 256, g->dRedI + 256, g->dRedV, g->dRedI);
+        double v = 0.0;
+        HIPCHK(hipMemcpyAsync(&v, g->dRedV + 256, sizeof(double), hipMemcpyDeviceToHost, g->s));
+        HIPCHK(hipStreamSynchronize(g->s));
+        g->fmin = v;
+        g->fmin_valid = true;
+    }
+    *fmin = g->fmin;
+    return 0;
+}
+
+static int run_acq(gp_ctx *g, int type, double par, double fmin, double y_mean, double y_std) {
+    if (g->P != 1) return fail(GP_ERR_ARG, "acquisitions need P == 1");
+    if (type < GP_ACQ_EI || type > GP_ACQ_MPI) return fail(GP_ERR_ARG, "unknown acquisition %d", type);
+    int rc;
+    if ((rc = ensure_out(g))) return rc;
+    if (!g->predicted || g->predicted_noise != 1)
+        if ((rc = run_predict(g, 1))) return rc;  // GPModel.predict: with_noise=True (gpmodel.py:102)
+    launch_acq(g->s, type, par, fmin, y_mean, y_std, g->dMean, g->dVar, g->M, g->dAcq);
+    return 0;
+}
+
+int gp_acq(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, double *out) {
+    if (!g || !out) return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = run_acq(g, type, par, fmin, y_mean, y_std))) return rc;
+    HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    return 0;
+}
+
+int gp_acq_argbest(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, int sense, int64_t *idx,
+                   double *val) {
+    if (!g || !idx || !val) return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    if (sense != 1 && sense != -1) return fail(GP_ERR_ARG, "sense must be +1 or -1");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = run_acq(g, type, par, fmin, y_mean, y_std))) return rc;
+    launch_argbest(g->s, g->dAcq, g->M, sense, g->dRedV + 256, g->dRedI + 256, g->dRedV, g->dRedI);
+    double v = 0.0;
+    long long i = 0;
+    HIPCHK(hipMemcpyAsync(&v, g->dRedV + 256, sizeof(double), hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipMemcpyAsync(&i, g->dRedI + 256, sizeof(long long), hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    *val = v;
+    *idx = (int64_t)i;
+    return 0;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------
+int gp_last_phases(gp_t *g, int cap, const char **names, double *ms, double *flops, double *bytes) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    hipSetDevice(g->device);
+    hipStreamSynchronize(g->s);
+    int n = std::min(cap, g->nphases);
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        hipEventElapsedTime(&t, g->phases[i].e0, g->phases[i].e1);
+        if (names) names[i] = g->phases[i].name;
+        if (ms) ms[i] = t;
+        if (flops) flops[i] = g->phases[i].flops;
+        if (bytes) bytes[i] = g->phases[i].bytes;
+    }
+    return n;
+}
+
+int gp_profile(gp_t *g, int on) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    g->profiling = on != 0;
+    g->gemm_ev_used = 0;
+    g->gemm_launches = 0;
+    g->gemm_flops = 0.0;
+    return 0;
+}
+
+int gp_gemm_stats(gp_t *g, int64_t *launches, double *ms, double *flops) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    hipSetDevice(g->device);
+    hipStreamSynchronize(g->s_panel);
+    hipStreamSynchronize(g->s);
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < g->gemm_ev_used; i += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g->gemm_events[i], g->gemm_events[i + 1]) == hipSuccess) tot += t;
+    }
+    if (launches) *launches = g->gemm_launches;
+    if (ms) *ms = tot;
+    if (flops) *flops = g->gemm_flops;
+    return 0;
+}
+
+// ---- multi-GPU --------------------------------------------------------------------------------------
+int gp_comm_unique_id(char *uid128) {
+    if (!uid128) return fail(GP_ERR_ARG, "null uid");
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(uid128, &id, 128);
+    return 0;
+}
+
+int gp_comm_init(gp_t *g, const char *uid128, int rank, int nranks) {
+    if (!g || !uid128) return fail(GP_ERR_ARG, "null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(GP_ERR_ARG, "bad rank %d / %d", rank, nranks);
+    HIPCHK(hipSetDevice(g->device));
+    if (g->comm) {
+        ncclCommDestroy(g->comm);
+        g->comm = nullptr;
+    }
+    ncclUniqueId id;
+    memcpy(&id, uid128, 128);
+    NCCLCHK(ncclCommInitRank(&g->comm, nranks, id, rank));
+    g->rank = rank;
+    g->nranks = nranks;
+    return 0;
+}
+
+int gp_comm_destroy(gp_t *g) {
+    if (!g) return 0;
+    if (g->comm) {
+        hipSetDevice(g->device);
+        ncclCommDestroy(g->comm);
+        g->comm = nullptr;
+    }
+    g->rank = 0;
+    g->nranks = 1;
+    return 0;
+}
+
+int gp_comm_allgather_best(gp_t *g, double val, int64_t idx, double *vals, int64_t *idxs) {
+    if (!g || !vals || !idxs) return fail(GP_ERR_ARG, "null argument");
+    if (!g->comm) return fail(GP_ERR_STATE, "gp_comm_init first");
+    if (g->nranks > 128) return fail(GP_ERR_ARG, "nranks > 128");
+    HIPCHK(hipSetDevice(g->device));
+    // one 16-byte record per rank: {double val, int64 idx} moved as 2 x 8 bytes
+    double *send = g->dRedV + 300;       // 2 doubles
+    double *recv = g->dRedV + 304;       // 2 * nranks doubles (<= 208 here: nranks <= 100)
+    if (2 * g->nranks > 200) return fail(GP_ERR_ARG, "nranks too large for the gather scratch");
+    double rec[2];
+    rec[0] = val;
+    memcpy(&rec[1], &idx, 8);
+    HIPCHK(hipMemcpyAsync(send, rec, 16, hipMemcpyHostToDevice, g->s));
+    NCCLCHK(ncclAllGather(send, recv, 2, ncclDouble, g->comm, g->s));
+    std::vector<double> out(2 * g->nranks);
+    HIPCHK(hipMemcpyAsync(out.data(), recv, 16 * g->nranks, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    for (int r = 0; r < g->nranks; ++r) {
+        vals[r] = out[2 * r];
+        memcpy(&idxs[r], &out[2 * r + 1], 8);
+    }
+    return 0;
+}
+
+int gp_comm_bcast_fit(gp_t *g, int root) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (!g->comm) return fail(GP_ERR_STATE, "gp_comm_init first");
+    if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "every rank needs data and params set");
+    HIPCHK(hipSetDevice(g->device));
+    const long Npad = g->Npad;
+    NCCLCHK(ncclGroupStart());
+    NCCLCHK(ncclBroadcast(g->dA, g->dA, (size_t)(Npad + GP_MAX_RHS) * Npad, ncclDouble, root, g->comm, g->s));
+    NCCLCHK(ncclBroadcast(g->dInvL, g->dInvL, (size_t)Npad * GP_TILE, ncclDouble, root, g->comm, g->s));
+    NCCLCHK(ncclBroadcast(g->dAlpha, g->dAlpha, (size_t)Npad * g->P, ncclDouble, root, g->comm, g->s));
+    NCCLCHK(ncclGroupEnd());
+    HIPCHK(hipStreamSynchronize(g->s));
+    g->fitted = true;
+    g->fmin_valid = false;
+    g->wi_valid = false;
+    g->predicted = false;
+    return 0;
+}
+
+// ---- not yet on the device (declared in the header; filled in by later milestones) -----------------
+int gp_get_woodbury_inv(gp_t *, double *) { return fail(GP_ERR_STATE, "gp_get_woodbury_inv: not built yet"); }
+int gp_lml_grad(gp_t *, double *, double *, double *) { return fail(GP_ERR_STATE, "gp_lml_grad: not built yet"); }
+int gp_predict_full_cov(gp_t *, int, double *, double *) { return fail(GP_ERR_STATE, "gp_predict_full_cov: not built yet"); }
+int gp_predict_grad(gp_t *, double *, double *) { return fail(GP_ERR_STATE, "gp_predict_grad: not built yet"); }
+int gp_acq_grad(gp_t *, int, double, double, double, double, double *, double *) {
+    return fail(GP_ERR_STATE, "gp_acq_grad: not built yet");
+}
+
+}  // extern "C"
+
+__global__ void add_diag_kernel(double *A, long lda, long N, double v) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) A[i * lda + i] += v;
+}
+void launch_add_diag(hipStream_t s, double *A, long lda, long N, double v) {
+    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, A, lda, N, v);
+}

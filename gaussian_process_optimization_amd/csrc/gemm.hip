@@ -1,0 +1,194 @@
+// fp64 MFMA "NT" GEMM for gfx950:  C (op)= A * B^T  over a set of 128x128 output tiles.
+//
+// This one kernel carries every dense contraction of the path:
+//   * Cholesky trailing update  A22 -= L21 L21^T      (dsyrk/dgemm inside LAPACK dpotrf,
+//                                                      reference call site GPy/GPy/util/linalg.py:58)
+//   * panel solve               L21  = A21 L11^-T     (as a product with the inverted diagonal tile)
+//   * candidate solve           T   -= T_J L_J^T, T_b = T_b L_bb^-T
+//                                                     (LAPACK dtrtrs, reference call site
+//                                                      GPy/GPy/inference/latent_function_inference/posterior.py:294)
+//
+// Layout: everything row-major fp64.  A rows and B rows both have the contraction index k
+// contiguous, so both operand tiles are staged the same way: 128 rows x BK(16) doubles per
+// stage, global -> registers (16 B per lane, 128 B contiguous per row) -> LDS with an 18-double
+// row pitch (16-B aligned rows; the operand fetch is one ds_read_b128 per lane = two k values
+// of row lane&15, at worst 2-way conflicted, which is <15 % LDS occupancy next to the MFMAs).
+//
+// Work decomposition: 256 threads = 4 waves as 2x2; each wave owns a 64x64 sub-tile =
+// 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  Per BK stage a wave issues 64 MFMAs
+// against 32 ds_read_b64, i.e. the matrix pipe is the only busy unit; the next stage's global
+// loads are issued before the MFMAs and written to the other LDS buffer after them (one
+// barrier per stage).  Two workgroups per CU (73.7 KB LDS each, <=256 VGPRs) keep a second
+// wave per SIMD ready while the first sits at the barrier or in the C epilogue.
+//
+// Roofline: algorithmic flops per launch = 2 * 128*128 * K * ntiles; bound = fp64 MFMA.
+#include "gphip_internal.h"
+
+#define BK 16
+#define LSTR 18  // LDS row pitch in doubles
+
+struct GemmArgs {
+    double *C;
+    long ldc;
+    const double *A;
+    long lda;
+    const double *B;
+    long ldb;
+    int b_mul;
+    int K;
+    int r0, r1, c0, c1, tri;
+};
+
+__device__ __forceinline__ void tile_from_linear(long t, const GemmArgs &a, int &i, int &c) {
+    if (!a.tri) {
+        int nr = a.r1 - a.r0;
+        c = a.c0 + (int)(t / nr);
+        i = a.r0 + (int)(t % nr);
+        return;
+    }
+    // column j = c - c0 holds H - j tiles (rows c .. r1-1), H = r1 - c0; prefix S(j) = j*H - j(j-1)/2
+    const long H = a.r1 - a.c0;
+    const double b = 2.0 * (double)H + 1.0;
+    long j = (long)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    if (j < 0) j = 0;
+    long S = j * H - j * (j - 1) / 2;
+    while (S > t) {
+        --j;
+        S = j * H - j * (j - 1) / 2;
+    }
+    while (S + (H - j) <= t) {
+        S += (H - j);
+        ++j;
+    }
+    c = a.c0 + (int)j;
+    i = c + (int)(t - S);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * 2 * GP_TILE * LSTR];  // [buf][A|B][128][18]
+
+    // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+    // run of the tile list so that neighbouring tiles (same A row panel) hit the same L2.
+    const long nwg = gridDim.x, bid = blockIdx.x;
+    const long q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const long wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+
+    int ti, tc;
+    tile_from_linear(wg, a, ti, tc);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const double *Ag = a.A + (long)ti * GP_TILE * a.lda;
+    const double *Bg = a.B + (long)tc * a.b_mul * GP_TILE * a.ldb;
+
+    // staging map: 128 rows x 8 chunks(16 B); thread handles rows (tid>>3) + 32q, chunk tid&7
+    const int srow = tid >> 3, sch = (tid & 7) * 2;
+    const double *ap = Ag + (long)srow * a.lda + sch;
+    const double *bp = Bg + (long)srow * a.ldb + sch;
+    const long a32 = 32 * a.lda, b32 = 32 * a.ldb;
+    const int soff = srow * LSTR + sch;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    double2_t ra[4], rb[4];
+    const int nk = a.K / BK;
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ra[q] = *(const double2_t *)(ap + q * a32);
+        rb[q] = *(const double2_t *)(bp + q * b32);
+    }
+    {
+        double *As = smem, *Bs = smem + GP_TILE * LSTR;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *(double2_t *)(As + soff + q * 32 * LSTR) = ra[q];
+            *(double2_t *)(Bs + soff + q * 32 * LSTR) = rb[q];
+        }
+    }
+    __syncthreads();
+
+    const int aoff = (wm * 64 + li) * LSTR + lg * 4;
+    const int boff = GP_TILE * LSTR + (wn * 64 + li) * LSTR + lg * 4;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            ap += BK;
+            bp += BK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ra[q] = *(const double2_t *)(ap + q * a32);
+                rb[q] = *(const double2_t *)(bp + q * b32);
+            }
+        }
+        const double *as = smem + buf * (2 * GP_TILE * LSTR) + aoff;
+        const double *bs = smem + buf * (2 * GP_TILE * LSTR) + boff;
+        // Lane group lg owns k = 4lg..4lg+3 of the stage; MFMA step (h,e) contracts k = 4g + 2h + e
+        // over the four lane groups g, so two ds_read_b128 per operand row-tile feed four MFMA steps.
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double2_t af[4], bf[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR + h * 2);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + h * 2);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m][e], bf[n][e], acc[m][n], 0, 0, 0);
+        }
+        if (more) {
+            double *As = smem + (buf ^ 1) * (2 * GP_TILE * LSTR), *Bs = As + GP_TILE * LSTR;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *(double2_t *)(As + soff + q * 32 * LSTR) = ra[q];
+                *(double2_t *)(Bs + soff + q * 32 * LSTR) = rb[q];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: accumulator element r of tile (m,n) is C[row = lg + 4r][col = li] of that 16x16 tile
+    double *Cg = a.C + ((long)ti * GP_TILE + wm * 64 + lg) * a.ldc + (long)tc * GP_TILE + wn * 64 + li;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double *p = Cg + (long)(m * 16 + 4 * r) * a.ldc + n * 16;
+                if (MODE == 0)
+                    *p = acc[m][n][r];
+                else
+                    *p = *p - acc[m][n][r];
+            }
+        }
+    }
+}
+
+void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *A, long lda,
+                    const double *B, long ldb, int b_mul, int K, TileSet ts) {
+    long n = tileset_count(ts);
+    if (n <= 0 || K <= 0) return;
+    GemmArgs a;
+    a.C = C; a.ldc = ldc; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
+    a.b_mul = b_mul; a.K = K;
+    a.r0 = ts.r0; a.r1 = ts.r1; a.c0 = ts.c0; a.c1 = ts.c1; a.tri = ts.tri;
+    if (mode == 0)
+        hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)n), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)n), dim3(256), 0, s, a);
+}

@@ -1,0 +1,81 @@
+// Internal declarations shared by the gphip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#define GP_TILE 128          // tile edge of every blocked algorithm (rows/cols per workgroup tile)
+#define GP_MAX_RHS 128       // RHS rows carried below the matrix (one tile)
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// ---- kernel parameters of the stationary covariance (device copy) ----------
+#define GP_MAX_D 64
+struct KernParams {
+    int kernel;            // GP_KERNEL_*
+    int D;
+    double variance;
+    double ls[GP_MAX_D];       // lengthscale per dimension (iso: all equal)
+};
+
+// ---- tile-set descriptor for the GEMM family ---------------------------------
+// Enumerates output tiles (i, c): c in [c0, c1); rows i in [tri ? c : r0, r1).
+struct TileSet {
+    int r0, r1, c0, c1, tri;
+};
+static inline long tileset_count(const TileSet &t) {
+    if (!t.tri) return (long)(t.r1 - t.r0) * (t.c1 - t.c0);
+    long n = 0;
+    for (int c = t.c0; c < t.c1; ++c) n += (t.r1 - c) > 0 ? (t.r1 - c) : 0;
+    return n;
+}
+
+// C tile (i,c) at C + i*128*ldc + c*128
+// A rows   at A + i*128*lda            (K columns)
+// B rows   at B + (c*b_mul)*128*ldb    (K columns)
+// mode 0: C = A B^T ; mode 1: C -= A B^T
+void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *A, long lda,
+                    const double *B, long ldb, int b_mul, int K, TileSet ts);
+
+// Factor the 128x128 diagonal tile t of A (row-major, lda) in place (lower) and write
+// its inverse (row-major 128x128, lower, zero above) to invL + t*128*128.
+// info: device int, 0 = ok, else 1-based global column of the first non-positive pivot.
+void launch_potrf_tile(hipStream_t s, double *A, long lda, int t, double *invL, int *info);
+
+// Ky lower tiles (incl. diagonal tiles in full) from X; padding rows get identity.
+void launch_kbuild(hipStream_t s, double *A, long lda, const double *X, long N, long Npad,
+                   const KernParams &kp, double diag_add, int full);
+// RHS rows: A[(Npad + p)*lda + i] = Y[i*P + p] (zero for i >= N, and rows p >= P zero)
+void launch_set_rhs(hipStream_t s, double *A, long lda, const double *Y, long N, long Npad, int P);
+// T[c*ldt + i] = k(xs_c, x_i) for c < M, i < N; zero in the padding.
+void launch_cross_k(hipStream_t s, double *T, long ldt, const double *Xs, long M, long Mpad,
+                    const double *X, long N, long Npad, const KernParams &kp);
+
+// logdet = 2 * sum_i log A[i*lda+i], i < N (deterministic single-block reduction)
+void launch_logdet(hipStream_t s, const double *A, long lda, long N, double *out);
+// out[p] = sum_i z_p[i]^2 for the RHS rows z_p = A[(Npad+p)*lda + i]
+void launch_rhs_sumsq(hipStream_t s, const double *A, long lda, long N, long Npad, int P, double *out);
+
+// Backward substitution alpha = L^-T z using the inverse diagonal tiles.
+//   z rows: Z + p*ldz (p < P), alpha rows: Aout + p*ldz; w: workspace P*Npad.
+void launch_trsv_backward(hipStream_t s, const double *L, long lda, const double *invL, long Npad,
+                          const double *Z, long ldz, int P, double *Aout, double *w);
+
+// Row reductions over the solved candidate rows T[c, 0:N]:
+//   var[c] = kss - sum_i T[c,i]^2 (+ noise_add), mean[c*P+p] = sum_i T[c,i] * Z[p*ldz + i]
+void launch_predict_reduce(hipStream_t s, const double *T, long ldt, long M, long N, const double *Z,
+                           long ldz, int P, double kss, double noise_add, double *mean, double *var);
+
+// mu[i] = sum_j k(x_i, x_j) alpha[j]  (posterior mean at the training inputs, K generated on the fly)
+void launch_train_mean(hipStream_t s, const double *X, long N, const KernParams &kp, const double *alpha,
+                       double *mu);
+// deterministic min / argbest reductions
+void launch_min(hipStream_t s, const double *v, long n, double *out);
+
+// acquisition values (negated) from mean/var; optional argbest
+void launch_acq(hipStream_t s, int type, double par, double fmin, double y_mean, double y_std,
+                const double *mean, const double *var, long M, double *out);
+void launch_argbest(hipStream_t s, const double *v, long n, int sense, double *best_val, long long *best_idx,
+                    double *scratch_val, long long *scratch_idx);

@@ -1,0 +1,156 @@
+// Covariance-matrix construction kernels (HBM-bound): K(X,X)+diag and K(Xs,X).
+//
+// Reference: Stationary._scaled_dist / _unscaled_dist (GPy/GPy/kern/src/stationary.py:155-193),
+// RBF.K_of_r (rbf.py:50-51), Matern52.K_of_r (stationary.py:575-576), and the diagonal term of
+// ExactGaussianInference (exact_gaussian_inference.py:55-56: Ky = K; diag += noise + 1e-8).
+//
+// The reference forms r^2 by the Gram trick (-2 X X^T + |x|^2 + |x'|^2, diagonal forced to 0,
+// clipped at 0).  Here r^2 = sum_d ((x_d - x'_d) / l_d)^2 is accumulated directly: D <= 64, the
+// inputs for a 128x128 output tile are 2 x 128 x D doubles staged once in LDS, and the direct
+// form has no cancellation (its diagonal is exactly 0 and it is never negative), so it sits
+// inside the reference's own rounding error.
+//
+// Tile = 128 x 128 outputs per 256-thread workgroup; a thread owns 2 adjacent columns (one
+// 16-B store, 1 KiB contiguous per wave-row) of 32 rows.  Algorithmic bytes: 8 N D read +
+// 8 N^2 / 2 written (lower tiles only).
+#include "gphip_internal.h"
+
+__device__ __forceinline__ double k_of_r2(int kernel, double variance, double r2) {
+    if (kernel == 0) {
+        return variance * exp(-0.5 * r2);
+    } else {
+        const double s5 = 2.23606797749978969640917366873128;  // sqrt(5)
+        const double r = sqrt(r2);
+        return variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * exp(-s5 * r);
+    }
+}
+
+// Stage rows [row0, row0+128) of X (N x D row-major) divided by the lengthscale (stationary.py:188-191) into LDS transposed: dst[d*128 + r].
+__device__ __forceinline__ void stage_rows_T(double *dst, const double *X, long row0, long N, int D,
+                                             const double *ls, int tid) {
+    for (int idx = tid; idx < GP_TILE * D; idx += 256) {
+        const int r = idx / D, d = idx - r * D;
+        const long g = row0 + r;
+        dst[d * GP_TILE + r] = (g < N) ? X[g * D + d] / ls[d] : 0.0;
+    }
+}
+
+// grid: lower tiles enumerated row-wise (tm >= tn): t = tm(tm+1)/2 + tn
+__global__ __launch_bounds__(256) void kbuild_kernel(double *A, long lda, const double *X, long N, long Npad,
+                                                     KernParams kp, double diag_add, int full, int nt) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xi = sm;                          // [D][128]
+    double *xj = sm + (long)kp.D * GP_TILE;   // [D][128]
+    __shared__ double ils[GP_MAX_D];
+    const int tid = threadIdx.x;
+    int tm, tn;
+    if (full) {
+        tm = blockIdx.x / nt;
+        tn = blockIdx.x % nt;
+    } else {
+        const long t = blockIdx.x;
+        tm = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long)tm * (tm + 1) / 2 > t) --tm;
+        while ((long)(tm + 1) * (tm + 2) / 2 <= t) ++tm;
+        tn = (int)(t - (long)tm * (tm + 1) / 2);
+    }
+    if (tid < kp.D) ils[tid] = kp.ls[tid];
+    __syncthreads();
+    stage_rows_T(xi, X, (long)tm * GP_TILE, N, kp.D, ils, tid);
+    stage_rows_T(xj, X, (long)tn * GP_TILE, N, kp.D, ils, tid);
+    __syncthreads();
+
+    const int cx = (tid & 63) * 2;   // two columns
+    const int ry = tid >> 6;         // rows ry + 4q
+    const long gc = (long)tn * GP_TILE + cx;
+    for (int q = 0; q < 32; ++q) {
+        const int r = ry + 4 * q;
+        const long gr = (long)tm * GP_TILE + r;
+        double s0 = 0.0, s1 = 0.0;
+        for (int d = 0; d < kp.D; ++d) {
+            const double a = xi[d * GP_TILE + r];
+            const double2_t b = *(const double2_t *)(xj + d * GP_TILE + cx);
+            const double d0 = a - b[0], d1 = a - b[1];
+            s0 = fma(d0, d0, s0);
+            s1 = fma(d1, d1, s1);
+        }
+        double2_t out;
+        out[0] = k_of_r2(kp.kernel, kp.variance, s0);
+        out[1] = k_of_r2(kp.kernel, kp.variance, s1);
+        // diagonal and padding
+        if (gr >= N) {
+            out[0] = (gr == gc) ? 1.0 : 0.0;
+            out[1] = (gr == gc + 1) ? 1.0 : 0.0;
+        } else {
+            if (gc >= N) out[0] = 0.0;
+            else if (gr == gc) out[0] = kp.variance + diag_add;
+            if (gc + 1 >= N) out[1] = 0.0;
+            else if (gr == gc + 1) out[1] = kp.variance + diag_add;
+        }
+        *(double2_t *)(A + gr * lda + gc) = out;
+    }
+}
+
+void launch_kbuild(hipStream_t s, double *A, long lda, const double *X, long N, long Npad,
+                   const KernParams &kp, double diag_add, int full) {
+    const int nt = (int)(Npad / GP_TILE);
+    const long nblk = full ? (long)nt * nt : (long)nt * (nt + 1) / 2;
+    const size_t shm = (size_t)2 * kp.D * GP_TILE * sizeof(double);
+    hipLaunchKernelGGL(kbuild_kernel, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp,
+                       diag_add, full, nt);
+}
+
+__global__ void set_rhs_kernel(double *A, long lda, const double *Y, long N, long Npad, int P) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.y;
+    if (i >= Npad) return;
+    A[(Npad + p) * lda + i] = (p < P && i < N) ? Y[i * P + p] : 0.0;
+}
+
+void launch_set_rhs(hipStream_t s, double *A, long lda, const double *Y, long N, long Npad, int P) {
+    dim3 grid((unsigned)((Npad + 255) / 256), GP_MAX_RHS);
+    hipLaunchKernelGGL(set_rhs_kernel, grid, dim3(256), 0, s, A, lda, Y, N, Npad, P);
+}
+
+// T[c][i] = k(xs_c, x_i); tiles (tc over candidates, ti over training points)
+__global__ __launch_bounds__(256) void cross_k_kernel(double *T, long ldt, const double *Xs, long M, const double *X,
+                                                      long N, KernParams kp, int nti) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xc = sm;
+    double *xt = sm + (long)kp.D * GP_TILE;
+    __shared__ double ils[GP_MAX_D];
+    const int tid = threadIdx.x;
+    const int tc = blockIdx.x / nti, ti = blockIdx.x % nti;
+    if (tid < kp.D) ils[tid] = kp.ls[tid];
+    __syncthreads();
+    stage_rows_T(xc, Xs, (long)tc * GP_TILE, M, kp.D, ils, tid);
+    stage_rows_T(xt, X, (long)ti * GP_TILE, N, kp.D, ils, tid);
+    __syncthreads();
+    const int cx = (tid & 63) * 2;
+    const int ry = tid >> 6;
+    const long gi = (long)ti * GP_TILE + cx;
+    for (int q = 0; q < 32; ++q) {
+        const int r = ry + 4 * q;
+        const long gcand = (long)tc * GP_TILE + r;
+        double s0 = 0.0, s1 = 0.0;
+        for (int d = 0; d < kp.D; ++d) {
+            const double a = xc[d * GP_TILE + r];
+            const double2_t b = *(const double2_t *)(xt + d * GP_TILE + cx);
+            const double d0 = a - b[0], d1 = a - b[1];
+            s0 = fma(d0, d0, s0);
+            s1 = fma(d1, d1, s1);
+        }
+        double2_t out;
+        out[0] = (gcand < M && gi < N) ? k_of_r2(kp.kernel, kp.variance, s0) : 0.0;
+        out[1] = (gcand < M && gi + 1 < N) ? k_of_r2(kp.kernel, kp.variance, s1) : 0.0;
+        *(double2_t *)(T + gcand * ldt + gi) = out;
+    }
+}
+
+void launch_cross_k(hipStream_t s, double *T, long ldt, const double *Xs, long M, long Mpad, const double *X,
+                    long N, long Npad, const KernParams &kp) {
+    const int ntc = (int)(Mpad / GP_TILE), nti = (int)(Npad / GP_TILE);
+    const size_t shm = (size_t)2 * kp.D * GP_TILE * sizeof(double);
+    hipLaunchKernelGGL(cross_k_kernel, dim3((unsigned)((long)ntc * nti)), dim3(256), shm, s, T, ldt, Xs, M, X, N,
+                       kp, nti);
+}

@@ -1,0 +1,286 @@
+// Vector-sized kernels around the factorisation: log-determinant, alpha back-substitution,
+// posterior reductions, training-set mean (fmin), acquisition values and arg-best.
+// All reductions are fixed-order (no float atomics) so results are bitwise reproducible.
+#include "gphip_internal.h"
+#include "../../include/gphip.h"
+
+// ---- block reduction helpers (256 or 1024 threads) ---------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < NT / 64; ++i) r += sh[i];
+        sh[0] = r;
+    }
+    __syncthreads();
+    r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// ---- logdet = 2 sum log L_ii  (GPy/GPy/util/linalg.py:208) --------------------------------
+__global__ __launch_bounds__(1024) void logdet_kernel(const double *A, long lda, long N, double *out) {
+    __shared__ double sh[16];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < N; i += 1024) s += log(A[i * lda + i]);
+    s = block_sum<1024>(s, sh);
+    if (threadIdx.x == 0) out[0] = 2.0 * s;
+}
+void launch_logdet(hipStream_t s, const double *A, long lda, long N, double *out) {
+    hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, s, A, lda, N, out);
+}
+
+// ---- out[p] = z_p . z_p  (= Y^T Ky^-1 Y, the data-fit term of exact_gaussian_inference.py:62) ----
+__global__ __launch_bounds__(1024) void rhs_sumsq_kernel(const double *A, long lda, long N, long Npad, double *out) {
+    __shared__ double sh[16];
+    const double *z = A + (Npad + blockIdx.x) * lda;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < N; i += 1024) s = fma(z[i], z[i], s);
+    s = block_sum<1024>(s, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+void launch_rhs_sumsq(hipStream_t s, const double *A, long lda, long N, long Npad, int P, double *out) {
+    hipLaunchKernelGGL(rhs_sumsq_kernel, dim3(P), dim3(1024), 0, s, A, lda, N, Npad, out);
+}
+
+// ---- alpha = L^-T z  (second half of dpotrs, exact_gaussian_inference.py:60) -------------------
+// Step k (row block k, from the bottom): every workgroup recomputes
+//   alpha_k = invL_kk^T (z_k - w_k)       (128x128 product against the inverted diagonal tile)
+// block j == k stores it; blocks j < k fold  w_j += L[k-block, j-block]^T alpha_k.
+__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const double *L, long lda, const double *invL, long Npad,
+                                                            const double *Z, long ldz, int P, double *Aout, double *w,
+                                                            int k) {
+    __shared__ double v[GP_TILE];
+    __shared__ double al[GP_TILE];
+    __shared__ double part[256];
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x;  // 0..k
+    const int c = tid & 127, h = tid >> 7;
+    const double *Ik = invL + (long)k * GP_TILE * GP_TILE;
+    for (int p = 0; p < P; ++p) {
+        if (tid < GP_TILE) v[tid] = Z[p * ldz + (long)k * GP_TILE + tid] - w[p * Npad + (long)k * GP_TILE + tid];
+        __syncthreads();
+        // alpha[c] = sum_r invL[r][c] v[r]; invL lower => r >= c
+        double s = 0.0;
+        for (int r = h * 64; r < h * 64 + 64; ++r) s = fma(Ik[r * GP_TILE + c], v[r], s);
+        part[tid] = s;
+        __syncthreads();
+        if (tid < GP_TILE) al[tid] = part[tid] + part[tid + 128];
+        __syncthreads();
+        if (j == k) {
+            if (tid < GP_TILE) Aout[p * ldz + (long)k * GP_TILE + tid] = al[tid];
+        } else {
+            const double *Lb = L + (long)k * GP_TILE * lda + (long)j * GP_TILE;
+            double u = 0.0;
+            for (int r = h * 64; r < h * 64 + 64; ++r) u = fma(Lb[(long)r * lda + c], al[r], u);
+            part[tid] = u;
+            __syncthreads();
+            if (tid < GP_TILE) w[p * Npad + (long)j * GP_TILE + tid] += part[tid] + part[tid + 128];
+        }
+        __syncthreads();
+    }
+}
+__global__ void zero_kernel(double *p, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+void launch_trsv_backward(hipStream_t s, const double *L, long lda, const double *invL, long Npad, const double *Z,
+                          long ldz, int P, double *Aout, double *w) {
+    const long nw = (long)P * Npad;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w, nw);
+    const int nt = (int)(Npad / GP_TILE);
+    for (int k = nt - 1; k >= 0; --k)
+        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k + 1), dim3(256), 0, s, L, lda, invL, Npad, Z, ldz, P, Aout, w,
+                           k);
+}
+
+// ---- posterior reductions (posterior.py:277,292-295; gaussian.py:109) --------------------------
+__global__ __launch_bounds__(256) void predict_reduce_kernel(const double *T, long ldt, long N, const double *Z,
+                                                             long ldz, int P, double kss, double noise_add,
+                                                             double *mean, double *var) {
+    __shared__ double sh[4];
+    const long c = blockIdx.x;
+    const double *t = T + c * ldt;
+    const long n2 = N >> 1;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n2; i += 256) {
+        const double2_t x = *(const double2_t *)(t + 2 * i);
+        s = fma(x[0], x[0], s);
+        s = fma(x[1], x[1], s);
+    }
+    if ((N & 1) && threadIdx.x == 0) s = fma(t[N - 1], t[N - 1], s);
+    s = block_sum<256>(s, sh);
+    if (threadIdx.x == 0) var[c] = (kss - s) + noise_add;
+    for (int p = 0; p < P; ++p) {
+        const double *z = Z + p * ldz;
+        double m = 0.0;
+        for (long i = threadIdx.x; i < n2; i += 256) {
+            const double2_t x = *(const double2_t *)(t + 2 * i);
+            const double2_t y = *(const double2_t *)(z + 2 * i);
+            m = fma(x[0], y[0], m);
+            m = fma(x[1], y[1], m);
+        }
+        if ((N & 1) && threadIdx.x == 0) m = fma(t[N - 1], z[N - 1], m);
+        m = block_sum<256>(m, sh);
+        if (threadIdx.x == 0) mean[c * P + p] = m;
+    }
+}
+void launch_predict_reduce(hipStream_t s, const double *T, long ldt, long M, long N, const double *Z, long ldz, int P,
+                           double kss, double noise_add, double *mean, double *var) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)M), dim3(256), 0, s, T, ldt, N, Z, ldz, P, kss, noise_add,
+                       mean, var);
+}
+
+// ---- posterior mean at the training inputs (GPModel.get_fmin, gpmodel.py:125-129) --------------
+__device__ __forceinline__ double k_of_r2_s(int kernel, double variance, double r2) {
+    if (kernel == 0) return variance * exp(-0.5 * r2);
+    const double s5 = 2.23606797749978969640917366873128;
+    const double r = sqrt(r2);
+    return variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * exp(-s5 * r);
+}
+#define TM_SPLIT 8
+// grid (N/128 row tiles, TM_SPLIT column slices); part[slice][i]
+__global__ __launch_bounds__(256) void train_mean_kernel(const double *X, long N, KernParams kp, const double *alpha,
+                                                         double *part) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xi = sm;                         // [D][128]
+    double *xj = sm + (long)kp.D * GP_TILE;  // [D][128]
+    double *aj = xj + (long)kp.D * GP_TILE;  // [128]
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int r = tid & 127, h = tid >> 7;
+    const long row0 = (long)blockIdx.x * GP_TILE;
+    const long ntile = (N + GP_TILE - 1) / GP_TILE;
+    for (int idx = tid; idx < GP_TILE * kp.D; idx += 256) {
+        const int rr = idx / kp.D, d = idx - rr * kp.D;
+        const long g = row0 + rr;
+        xi[d * GP_TILE + rr] = (g < N) ? X[g * kp.D + d] / kp.ls[d] : 0.0;
+    }
+    double acc = 0.0;
+    for (long tj = blockIdx.y; tj < ntile; tj += TM_SPLIT) {
+        __syncthreads();
+        for (int idx = tid; idx < GP_TILE * kp.D; idx += 256) {
+            const int rr = idx / kp.D, d = idx - rr * kp.D;
+            const long g = tj * GP_TILE + rr;
+            xj[d * GP_TILE + rr] = (g < N) ? X[g * kp.D + d] / kp.ls[d] : 0.0;
+        }
+        if (tid < GP_TILE) {
+            const long g = tj * GP_TILE + tid;
+            aj[tid] = (g < N) ? alpha[g] : 0.0;
+        }
+        __syncthreads();
+        for (int jj = h * 64; jj < h * 64 + 64; ++jj) {
+            double s = 0.0;
+            for (int d = 0; d < kp.D; ++d) {
+                const double df = xi[d * GP_TILE + r] - xj[d * GP_TILE + jj];
+                s = fma(df, df, s);
+            }
+            acc = fma(k_of_r2_s(kp.kernel, kp.variance, s), aj[jj], acc);
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < GP_TILE && row0 + tid < N) part[(long)blockIdx.y * N + row0 + tid] = red[tid] + red[tid + 128];
+}
+__global__ void train_mean_sum_kernel(const double *part, long N, double *mu) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double s = 0.0;
+    for (int q = 0; q < TM_SPLIT; ++q) s += part[(long)q * N + i];
+    mu[i] = s;
+}
+// mu must have room for (TM_SPLIT + 1) * N doubles: [mu | partials]
+void launch_train_mean(hipStream_t s, const double *X, long N, const KernParams &kp, const double *alpha, double *mu) {
+    const size_t shm = ((size_t)2 * kp.D * GP_TILE + GP_TILE) * sizeof(double);
+    dim3 grid((unsigned)((N + GP_TILE - 1) / GP_TILE), TM_SPLIT);
+    hipLaunchKernelGGL(train_mean_kernel, grid, dim3(256), shm, s, X, N, kp, alpha, mu + N);
+    hipLaunchKernelGGL(train_mean_sum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, mu + N, N, mu);
+}
+
+// ---- min / arg-best (NumPy tie rule: lowest index) -------------------------------------------
+__device__ __forceinline__ void best_combine(double &v, long long &i, double v2, long long i2, int sense) {
+    // sense +1: larger wins; -1: smaller wins; ties -> lower index
+    const bool better = (sense > 0) ? (v2 > v) : (v2 < v);
+    if (better || (v2 == v && i2 < i)) {
+        v = v2;
+        i = i2;
+    }
+}
+__global__ __launch_bounds__(256) void argbest_kernel(const double *x, long n, int sense, double *ov, long long *oi,
+                                                      const long long *in_idx) {
+    __shared__ double sv[256];
+    __shared__ long long si[256];
+    const int tid = threadIdx.x;
+    double v = (sense > 0) ? -INFINITY : INFINITY;
+    long long bi = 0x7fffffffffffffffLL;
+    for (long i = (long)blockIdx.x * 256 + tid; i < n; i += (long)gridDim.x * 256)
+        best_combine(v, bi, x[i], in_idx ? in_idx[i] : (long long)i, sense);
+    sv[tid] = v;
+    si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) best_combine(sv[tid], si[tid], sv[tid + o], si[tid + o], sense);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ov[blockIdx.x] = sv[0];
+        oi[blockIdx.x] = si[0];
+    }
+}
+// scratch_val / scratch_idx: >= 256 entries
+void launch_argbest(hipStream_t s, const double *v, long n, int sense, double *best_val, long long *best_idx,
+                    double *scratch_val, long long *scratch_idx) {
+    int nb = (int)((n + 255) / 256);
+    if (nb > 256) nb = 256;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(argbest_kernel, dim3(nb), dim3(256), 0, s, v, n, sense, scratch_val, scratch_idx,
+                       (const long long *)nullptr);
+    hipLaunchKernelGGL(argbest_kernel, dim3(1), dim3(256), 0, s, scratch_val, (long)nb, sense, best_val, best_idx,
+                       (const long long *)scratch_idx);
+}
+void launch_min(hipStream_t s, const double *v, long n, double *out) {
+    // out: [0] = min, scratch after it: needs 1 + 256 doubles and 257 long longs behind (see api)
+    double *sv = out + 1;
+    long long *si = (long long *)(out + 1 + 256);
+    launch_argbest(s, v, n, -1, out, si + 256, sv, si);
+}
+
+// ---- acquisition values (GPyOpt acquisitions/{EI,LCB,MPI}.py, util/general.py:113-129) --------
+__global__ void acq_kernel(int type, double par, double fmin, double y_mean, double y_std, const double *mean,
+                           const double *var, long M, double *out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    // GP.predict un-normalisation (gp.py:344-352) then GPModel._predict clip (gpmodel.py:99)
+    const double m = mean[i] * y_std + y_mean;
+    double v = var[i] * (y_std * y_std);
+    v = (v < 1e-10) ? 1e-10 : v;
+    double s = sqrt(v);
+    double f;
+    if (type == GP_ACQ_LCB) {
+        f = -m + par * s;  // LCB.py:36
+    } else {
+        if (s < 1e-10) s = 1e-10;  // general.py:121-124
+        const double u = (fmin - m - par) / s;
+        const double phi = exp(-0.5 * u * u) / 2.50662827463100050241576528481105;  // sqrt(2 pi)
+        const double Phi = 0.5 * erfc(-u / 1.41421356237309504880168872420970);
+        f = (type == GP_ACQ_EI) ? s * (u * Phi + phi) : Phi;  // EI.py:39 / MPI.py:39
+    }
+    out[i] = -f;  // acquisitions/base.py:39 (cost 1, no constraints)
+}
+void launch_acq(hipStream_t s, int type, double par, double fmin, double y_mean, double y_std, const double *mean,
+                const double *var, long M, double *out) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(acq_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, type, par, fmin, y_mean, y_std,
+                       mean, var, M, out);
+}

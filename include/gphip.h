@@ -1,0 +1,162 @@
+/*
+ * gphip.h -- C ABI of libgphip.so: the MI355X-native (gfx950) exact-GP hot path.
+ *
+ * Drop-in boundary for the GPy / GPyOpt path named in BASELINE.json:north_star.
+ * Each entry point cites the reference interface it replaces (paths relative
+ * to the reference tree, file:line).  Plain pointers and sizes only; all
+ * matrices are float64, C-contiguous (row-major), owned by the caller.  The
+ * library copies host->device, owns all device memory inside the opaque
+ * gp_t, writes results into caller-allocated buffers and keeps no host
+ * pointer after returning.  One gp_t per device; calls are synchronous; a
+ * gp_t is not thread-safe, distinct gp_t may be used from distinct threads.
+ *
+ * Return codes: 0 = OK; k > 0 = leading minor k of Ky is not positive
+ * definite even after the reference's jitter ladder (the host raises
+ * numpy.linalg.LinAlgError with the reference's messages, GPy/GPy/util/
+ * linalg.py:62-75); < 0 = bad argument / HIP / RCCL error (message via
+ * gp_last_error()).  The library never aborts the process.
+ */
+#ifndef GPHIP_H
+#define GPHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gp_ctx gp_t;
+
+/* kernel families: GPy/GPy/kern/src/rbf.py:12-57, stationary.py:546-579 */
+#define GP_KERNEL_RBF 0
+#define GP_KERNEL_MATERN52 1
+
+/* acquisitions: GPyOpt/GPyOpt/acquisitions/{EI,LCB,MPI}.py */
+#define GP_ACQ_EI 0
+#define GP_ACQ_LCB 1
+#define GP_ACQ_MPI 2
+
+/* error codes (< 0) */
+#define GP_ERR_ARG (-1)
+#define GP_ERR_HIP (-2)
+#define GP_ERR_STATE (-3)
+#define GP_ERR_RCCL (-4)
+#define GP_ERR_NOT_PD_DIAG (-5) /* "not pd: non-positive diagonal elements", linalg.py:63-64 */
+
+/* ---- library / device -------------------------------------------------- */
+const char *gp_last_error(void);
+const char *gp_version(void);
+int gp_device_count(int *count);
+/* fills name (<= cap bytes), compute units, HBM bytes */
+int gp_device_info(int device, char *name, int cap, int *cus, int64_t *hbm_bytes);
+
+/* ---- lifetime ---------------------------------------------------------- */
+/* Replaces constructing GPy.models.GPRegression / GP (GPy/GPy/models/gp_regression.py:29-36,
+ * GPy/GPy/core/gp.py:38-110): an empty model bound to one device. */
+int gp_create(gp_t **out, int device);
+int gp_destroy(gp_t *gp);
+
+/* GP.set_XY (GPy/GPy/core/gp.py:202-238): X[N,D], Y[N,P] row-major, copied H2D. 1 <= P <= 128. */
+int gp_set_data(gp_t *gp, const double *X, const double *Y, int64_t N, int D, int P);
+
+/* Kernel + Gaussian-noise hyper-parameters in natural space
+ * (Stationary.__init__ stationary.py:61-82; Gaussian variance likelihoods/gaussian.py:43).
+ * lengthscale has 1 entry (ard = 0) or D entries (ard = 1). */
+int gp_set_params(gp_t *gp, int kernel, int ard, double variance, const double *lengthscale, double noise);
+
+/* ---- fit ---------------------------------------------------------------
+ * ExactGaussianInference.inference (GPy/GPy/inference/latent_function_inference/
+ * exact_gaussian_inference.py:37-74) minus the gradient terms:
+ *   K = kern.K(X) (stationary.py:107-193); Ky = K + (noise + 1e-8) I (:55-56);
+ *   L = jitchol(Ky, maxtries) with the reference's jitter ladder (linalg.py:56-81);
+ *   logdet = 2 sum log L_ii (linalg.py:208); alpha = Ky^-1 Y (dpotrs, :60);
+ *   lml = 0.5 (-N P log 2pi - P logdet - sum(alpha * Y)) (:62).
+ * Outputs: *lml, *logdet, *jitter_used (0 when the first dpotrf succeeds). */
+int gp_fit(gp_t *gp, int maxtries, double *lml, double *logdet, double *jitter_used);
+
+/* Posterior.woodbury_vector (posterior.py:198-214): alpha[N,P]. */
+int gp_get_alpha(gp_t *gp, double *alpha);
+/* Posterior.woodbury_chol: L[N,N] row-major, lower triangle (upper written as 0). */
+int gp_get_chol(gp_t *gp, double *L);
+/* Posterior.woodbury_inv (posterior.py:176-196): Ky^-1 [N,N], symmetric.  Computed lazily (potri). */
+int gp_get_woodbury_inv(gp_t *gp, double *Wi);
+/* kern.K(X) without noise (stationary.py:107-140), for parity tests of the K-build kernel: K[N,N]. */
+int gp_kernel_matrix(gp_t *gp, double *K);
+
+/* GP.parameters_changed gradient push-down (gp.py:268-269):
+ *   dL_dK = 0.5 (alpha alpha^T - P Ky^-1) (exact_gaussian_inference.py:70);
+ *   dnoise = sum diag(dL_dK) (gaussian.py:78-79);
+ *   dvariance, dlengthscale[1 or D] = Stationary.update_gradients_full (stationary.py:218-238).
+ * Natural-space gradients of the LML; the Logexp chain rule stays on the host. Requires gp_fit. */
+int gp_lml_grad(gp_t *gp, double *dvariance, double *dlengthscale, double *dnoise);
+
+/* ---- predict -----------------------------------------------------------
+ * Candidates Xs[M,D] are made resident once; the calls below then run on them. */
+int gp_set_candidates(gp_t *gp, const double *Xs, int64_t M);
+
+/* PosteriorExact._raw_predict (posterior.py:273-302, full_cov = False) followed by
+ * Gaussian.predictive_values (likelihoods/gaussian.py:102-110) when include_noise != 0:
+ *   mean[M,P] = K(Xs,X) alpha;  var[M] = variance - sum_rows (L^-1 K(X,Xs))^2 (+ noise).  No clipping. */
+int gp_predict(gp_t *gp, int include_noise, double *mean, double *var);
+
+/* full_cov = True branch (posterior.py:280-284): cov[M,M] = K(Xs) - tmp^T tmp (+ noise I). */
+int gp_predict_full_cov(gp_t *gp, int include_noise, double *mean, double *cov);
+
+/* GP.predictive_gradients (gp.py:407-454): dmdx[M,D,P], dvdx[M,D]. */
+int gp_predict_grad(gp_t *gp, double *dmdx, double *dvdx);
+
+/* GPModel.get_fmin (GPyOpt/GPyOpt/models/gpmodel.py:125-129): min over the training
+ * inputs of the posterior mean.  Cached per fit (the reference recomputes it per call). */
+int gp_fmin(gp_t *gp, double *fmin);
+
+/* AcquisitionBase.acquisition_function on the resident candidates
+ * (GPyOpt/GPyOpt/acquisitions/base.py:33-39 with constant cost and no constraints):
+ * GPModel.predict (gpmodel.py:95-112: var clipped at 1e-10, s = sqrt(v), with noise),
+ * get_quantiles (util/general.py:113-129), EI.py:32-40 / LCB.py:31-37 / MPI.py:32-40.
+ * par = jitter (EI, MPI) or exploration weight (LCB).  Requires P == 1.
+ * y_mean / y_std undo a host-side Standardize normalizer (1 / 0 when none).
+ * out[M] holds the NEGATED acquisition, as the reference returns it. */
+int gp_acq(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std, double *out);
+
+/* Same scores reduced on the device: sense = +1 -> argmax of out, -1 -> argmin of out
+ * (run.py:1240-1241 takes argmax; anchor_points_generator.py:61 takes the smallest);
+ * ties resolve to the lowest index (NumPy argmax/argmin). idx is relative to this gp's
+ * candidate set. */
+int gp_acq_argbest(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std,
+                   int sense, int64_t *idx, double *val);
+
+/* acquisition_function_withGradients (base.py:42-50; EI.py:42-51, LCB.py:39-46, MPI.py:42-51):
+ * out[M] negated value, dout[M,D] negated gradient. */
+int gp_acq_grad(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std,
+                double *out, double *dout);
+
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI) ---------------------
+ * The candidate table shards across ranks; every rank holds a replica of the
+ * fitted model.  uid is ncclUniqueId (128 bytes) produced on rank 0 and carried
+ * to the other ranks by the launcher (any side channel). */
+int gp_comm_unique_id(char *uid128);
+int gp_comm_init(gp_t *gp, const char *uid128, int rank, int nranks);
+int gp_comm_destroy(gp_t *gp);
+/* all-gather of one (val, idx) pair per rank: vals[nranks], idxs[nranks]. */
+int gp_comm_allgather_best(gp_t *gp, double val, int64_t idx, double *vals, int64_t *idxs);
+/* broadcast of a fitted model's factor from root to all ranks (L, alpha, z, inverse tiles). */
+int gp_comm_bcast_fit(gp_t *gp, int root);
+
+/* ---- measurement ---------------------------------------------------------
+ * Phase timings of the last gp_fit / gp_predict measured with HIP events on the
+ * library's stream; names[i] is a static string, ms[i] milliseconds, flops[i] the
+ * algorithmic flop count of the phase (0 for bandwidth phases), bytes[i] its
+ * algorithmic bytes.  Returns the number of phases written (<= cap). */
+int gp_last_phases(gp_t *gp, int cap, const char **names, double *ms, double *flops, double *bytes);
+/* Dominant-kernel accounting (the fp64 MFMA GEMM): launches, summed device time (ms, HIP
+ * events around every launch when profiling is on), algorithmic flops.  Reset by gp_profile(gp, 1). */
+int gp_profile(gp_t *gp, int on);
+int gp_gemm_stats(gp_t *gp, int64_t *launches, double *ms, double *flops);
+int gp_synchronize(gp_t *gp);
+/* tunables: "panel_tiles" (outer panel width in 128-tiles), "lookahead" (0/1), "mc_max" */
+int gp_set_option(gp_t *gp, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPHIP_H */

@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X: GP fit+predict iterations/s at N=16384, D=8.
+
+A "step" is one pass of the hot path over one batch of synthetic input:
+    gp_fit   (K build -> Cholesky -> alpha -> LML)                     SURVEY.md 8a rows A1-A5
+    gp_predict on the rank's 10 000 resident candidates                 rows A6-A7
+    EI scoring of those candidates + device arg-best                    rows A9-A11, A14
+    (N > 1) one RCCL all-gather of the per-shard (best, index) pair     SURVEY.md 8e
+Inputs are resident in HBM before the timed region; hyper-parameters are fixed.
+
+Multi-GPU (one process per GPU, launched by torch.distributed.run): the candidate table shards
+across ranks, the fit is REPLICATED on every rank ("replicas only" for the fit), so
+per-GPU work is fixed as N grows ("weak").  `value` counts the fit+predict units all ranks
+processed per second; config.job_iters_per_s is the rate of whole sharded iterations.
+torch is imported only for N > 1 (rendezvous + barrier over gloo); the data path is libgphip
+(ctypes) and its RCCL communicator.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X vendor dense FP64 matrix peak (v_mfma_f64_16x16x4_f64); see DESIGN.md
+
+
+def synthetic(N, D, M, seed=1234, cand_seed=None):
+    """SURVEY.md 8(d) generators (same as oracle.cpu_ref.synthetic_problem, restated so that the timed
+    product path never touches oracle/)."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (N, D))
+    f = np.sin(2 * np.pi * X).sum(1, keepdims=True) / np.sqrt(D)
+    Y = f + 0.05 * np.random.default_rng(seed + 1).standard_normal((N, 1))
+    Y = (Y - Y.mean()) / Y.std()
+    Xs = np.random.default_rng(seed + 2 if cand_seed is None else cand_seed).uniform(0, 1, (M, D))
+    return X, Y, Xs
+
+
+def cpu_baseline(N, D, M):
+    """The oracle (NumPy/SciPy restatement of the reference's path) timed on this host, on a bounded
+    sample: N/2, M/2 of the same workload = 1/8 of its flops; the time is scaled by that ratio."""
+    from oracle import cpu_ref as O
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [(d.get("internal_api"), d.get("num_threads")) for d in threadpool_info()]
+        cores = max([n for _, n in blas if n] or [os.cpu_count()])
+    except Exception:  # noqa: BLE001
+        blas, cores = [], os.cpu_count()
+    Ns, Ms = N // 2, M // 2
+    X, Y, Xs = O.synthetic_problem(Ns, D, Ms, seed=1234)
+    kern = O.RBF(D, 1.0, O.default_lengthscale(D, False))
+    t0 = time.perf_counter()
+    lml, mu, var, phases = O.fit_predict_iteration(kern, X, Y, 1e-2, Xs, as_gpy=False)
+    t = time.perf_counter() - t0
+    flops_full = N ** 3 / 3.0 + float(N) * N * M
+    flops_s = Ns ** 3 / 3.0 + float(Ns) * Ns * Ms
+    scale = flops_full / flops_s
+    return {"value": 1.0 / (t * scale), "unit": "fit+predict iters/s", "cores": int(cores), "kind": "port",
+            "sample": "N=%d, M=%d (1/%.0f of the flops of N=%d, M=%d), minimal path (K, dpotrf, dpotrs, K*, dtrtrs); "
+                      "measured %.2f s, scaled by %.1f" % (Ns, Ms, scale, N, M, t, scale),
+            "phases_s": {k: round(v, 3) for k, v in phases.items()}, "blas": blas}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--N", type=int, default=16384)
+    ap.add_argument("--D", type=int, default=8)
+    ap.add_argument("--M", type=int, default=10000, help="candidates per GPU")
+    ap.add_argument("--kernel", default="rbf", choices=["rbf", "Mat52"])
+    ap.add_argument("--panel-tiles", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # plumbing only: rendezvous, barrier, max-over-ranks
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from gaussian_process_optimization_amd import _lib
+    h = _lib.Handle(local_rank)
+    if args.panel_tiles:
+        h.set_option("panel_tiles", args.panel_tiles)
+    N, D, M = args.N, args.D, args.M
+    X, Y, Xs = synthetic(N, D, M, cand_seed=1236 + rank)   # every rank: same model data, its own candidate shard
+    kid = _lib.GP_KERNEL_RBF if args.kernel == "rbf" else _lib.GP_KERNEL_MATERN52
+    h.set_data(X, Y)
+    h.set_params(kid, 0, 1.0, [0.25 * np.sqrt(D)], 1e-2)
+    h.set_candidates(Xs)
+    if world > 1:
+        import torch
+        uid = [h.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init(uid[0], rank, world)
+
+    def barrier():
+        h.synchronize()
+        if dist is not None:
+            dist.barrier()
+        h.synchronize()
+
+    def step():
+        lml, logdet, jit = h.fit()
+        mu, var = h.predict(True)
+        fmin = h.fmin()
+        idx, val = h.acq_argbest(_lib.GP_ACQ_EI, 0.01, fmin, -1)
+        if world > 1:
+            vals, idxs = h.comm_allgather_best(val, rank * M + idx, world)
+            from gaussian_process_optimization_amd.sharded import merge_best
+            idx, val = merge_best(vals, idxs, -1)
+        return lml, idx, val
+
+    for _ in range(args.warmup):
+        out = step()
+    h.profile(True)          # HIP events around every launch of the dominant kernel (fp64 MFMA GEMM)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    gs = h.gemm_stats()
+    h.profile(False)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # one more un-timed step for the phase breakdown
+    h.fit()
+    ph_fit = h.phases()
+    h.predict(True)
+    ph_pred = h.phases()
+    phases = {p["name"]: round(p["ms"], 3) for p in ph_fit + ph_pred}
+    chol = [p for p in ph_fit if p["name"] == "cholesky"][0]
+    solve = [p for p in ph_pred if p["name"] == "cand_solve"][0]
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        job_rate = args.steps / elapsed
+        achieved = gs["flops"] / max(gs["ms"], 1e-9) / 1e9
+        result = {
+            "metric": "GP fit+predict iters/sec at N=%d D=%d" % (N, D),
+            "value": world * job_rate,
+            "unit": "fit+predict iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3: N=%d, D=%d %s iso, fit (K, Cholesky, alpha, LML) + predict mean/var at "
+                                   "M=%d candidates per GPU + EI arg-best" % (N, D, args.kernel, M),
+                       "noise": 1e-2, "candidates_per_gpu": M, "fit": "replicated on every rank",
+                       "job_iters_per_s": job_rate, "lml": out[0], "best_candidate": int(out[1]),
+                       "phases_ms": phases,
+                       "cholesky_tflops": chol["flops"] / chol["ms"] / 1e9,
+                       "cholesky_frac_of_fp64_mfma_peak": chol["flops"] / chol["ms"] / 1e9 / FP64_MFMA_PEAK_TFLOPS,
+                       "cand_solve_tflops": solve["flops"] / solve["ms"] / 1e9},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (fp64 v_mfma_f64_16x16x4_f64)",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": gs["launches"], "kernel_ms_total": gs["ms"],
+                         "flops_per_launch_avg": gs["flops"] / max(gs["launches"], 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(N, D, M)
+        print(json.dumps(result))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    h.close()
+
+
+if __name__ == "__main__":
+    main()

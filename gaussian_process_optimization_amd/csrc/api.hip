@@ -84,6 +84,10 @@ struct gp_ctx {
     double *dWi = nullptr;
     long capWi = 0;
     bool wi_valid = false;
+    double *dT2 = nullptr;
+    long capT2 = 0;
+    double *dDm = nullptr, *dDv = nullptr, *dDacq = nullptr;
+    long capD = 0;
     // options
     int panel_tiles = 4;
     int lookahead = 0;
@@ -100,8 +104,6 @@ struct gp_ctx {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
 };
-
-void launch_add_diag(hipStream_t s, double *A, long lda, long N, double v);
 
 static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
 
@@ -126,7 +128,7 @@ static void phase_end(gp_ctx *g, int id) {
 
 // ---- GEMM wrapper with accounting ---------------------------------------------------------------
 static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const double *A, long lda, const double *B,
-                 long ldb, int b_mul, int K, TileSet ts) {
+                 long ldb, int b_mul, int K, TileSet ts, int k_tri = 0) {
     const long n = tileset_count(ts);
     if (n <= 0 || K <= 0) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -142,10 +144,10 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
         e1 = g->gemm_events[g->gemm_ev_used++];
         hipEventRecord(e0, s);
     }
-    launch_gemm_nt(s, mode, C, ldc, A, lda, B, ldb, b_mul, K, ts);
+    launch_gemm_nt(s, mode, C, ldc, A, lda, B, ldb, b_mul, K, ts, k_tri);
     if (g->profiling) hipEventRecord(e1, s);
     g->gemm_launches++;
-    g->gemm_flops += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n;
+    g->gemm_flops += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n * (k_tri ? 0.5 : 1.0);
 }
 
 // ---- memory helpers -----------------------------------------------------------------------------
@@ -216,7 +218,7 @@ int gp_destroy(gp_t *g) {
     hipDeviceSynchronize();
     if (g->comm) ncclCommDestroy(g->comm);
     double *ptrs[] = {g->dX, g->dY, g->dA, g->dInvL, g->dAlpha, g->dW, g->dMu, g->dScal, g->dRedV,
-                      g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi};
+                      g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi, g->dT2, g->dDm, g->dDv, g->dDacq};
     for (double *p : ptrs)
         if (p) hipFree(p);
     if (g->dInfo) hipFree(g->dInfo);
@@ -742,21 +744,191 @@ int gp_comm_bcast_fit(gp_t *g, int root) {
     return 0;
 }
 
-// ---- not yet on the device (declared in the header; filled in by later milestones) -----------------
-int gp_get_woodbury_inv(gp_t *, double *) { return fail(GP_ERR_STATE, "gp_get_woodbury_inv: not built yet"); }
-int gp_lml_grad(gp_t *, double *, double *, double *) { return fail(GP_ERR_STATE, "gp_lml_grad: not built yet"); }
-int gp_predict_full_cov(gp_t *, int, double *, double *) { return fail(GP_ERR_STATE, "gp_predict_full_cov: not built yet"); }
-int gp_predict_grad(gp_t *, double *, double *) { return fail(GP_ERR_STATE, "gp_predict_grad: not built yet"); }
-int gp_acq_grad(gp_t *, int, double, double, double, double, double *, double *) {
-    return fail(GP_ERR_STATE, "gp_acq_grad: not built yet");
+// ---- Ky^-1 (potri-equivalent): dtrtri + dlauum re-expressed on the NT GEMM -------------------------
+// W = L^-T is the candidate solve applied to the identity (row c of W = (L^-1 e_c)^T); rows above
+// the current panel are still zero, so the tile sets are trapezoids and the cost is N^3/3.
+// Ky^-1 = W W^T with the contraction of tile row a starting at column a*128: another N^3/3.
+// Reference: pdinv / dpotri (GPy/GPy/util/linalg.py:127-145,193-214), Posterior.woodbury_inv
+// (posterior.py:176-196).
+static int ensure_wi(gp_ctx *g) {
+    if (g->wi_valid) return 0;
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    const long Npad = g->Npad, lda = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    const int Wt = g->panel_tiles;
+    int rc;
+    if ((rc = dev_realloc(&g->dT, &g->capT, Npad * Npad))) return rc;
+    if ((rc = dev_realloc(&g->dWi, &g->capWi, Npad * Npad))) return rc;
+    double *T = g->dT;
+    const double *L = g->dA;
+    hipStream_t s = g->s;
+    int ph = phase_begin(g, "potri", 2.0 * (double)g->N * g->N * g->N / 3.0, 0.0);
+    launch_set_identity(s, T, Npad, Npad);
+    for (int J0 = 0; J0 < nt; J0 += Wt) {
+        const int J1 = std::min(J0 + Wt, nt);
+        for (int b = J0; b < J1; ++b) {
+            gemm(g, s, 0, T, Npad, T + (long)b * GP_TILE, Npad, g->dInvL + (long)b * GP_TILE * GP_TILE, GP_TILE, 0,
+                 GP_TILE, TileSet{0, b + 1, b, b + 1, 0});
+            if (b + 1 < J1)
+                gemm(g, s, 1, T, Npad, T + (long)b * GP_TILE, Npad, L + (long)b * GP_TILE, lda, 1, GP_TILE,
+                     TileSet{0, b + 1, b + 1, J1, 0});
+        }
+        if (J1 < nt)
+            gemm(g, s, 1, T, Npad, T + (long)J0 * GP_TILE, Npad, L + (long)J0 * GP_TILE, lda, 1, (J1 - J0) * GP_TILE,
+                 TileSet{0, J1, J1, nt, 0});
+    }
+    gemm(g, s, 0, g->dWi, Npad, T, Npad, T, Npad, 1, (int)Npad, TileSet{0, nt, 0, nt, 1}, 1);
+    launch_symmetrize(s, g->dWi, Npad, Npad);
+    phase_end(g, ph);
+    g->wi_valid = true;
+    g->predicted = false;  // dT was reused
+    return 0;
+}
+
+int gp_get_woodbury_inv(gp_t *g, double *Wi) {
+    if (!g || !Wi) return fail(GP_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = ensure_wi(g))) return rc;
+    HIPCHK(hipStreamSynchronize(g->s));
+    HIPCHK(hipMemcpy2D(Wi, sizeof(double) * g->N, g->dWi, sizeof(double) * g->Npad, sizeof(double) * g->N, g->N,
+                       hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int gp_lml_grad(gp_t *g, double *dvariance, double *dlengthscale, double *dnoise) {
+    if (!g || !dvariance || !dlengthscale || !dnoise) return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    g->nphases = 0;
+    if ((rc = ensure_wi(g))) return rc;
+    const long Npad = g->Npad;
+    const int nt = (int)(Npad / GP_TILE), D = g->D;
+    const long ntile = (long)nt * (nt + 1) / 2;
+    // per-tile partials live in dT (free after ensure_wi): ntile * NACC doubles << Npad^2
+    double *partial = g->dT;
+    int ph = phase_begin(g, "lml_grad", 0.0, 8.0 * (double)g->N * g->N / 2);
+    std::vector<double> host((size_t)GP_GRAD_NACC * ((D + GP_GRAD_CH - 1) / GP_GRAD_CH));
+    int pass = 0;
+    for (int d0 = 0; d0 < D; d0 += GP_GRAD_CH, ++pass) {
+        launch_lml_grad(g->s, g->dX, g->N, Npad, g->kp, g->ard, d0, g->dAlpha, g->P, g->dWi, Npad, partial,
+                        g->dScal + 64 + pass * GP_GRAD_NACC);
+        if (!g->ard) break;
+    }
+    phase_end(g, ph);
+    const int npass = g->ard ? (D + GP_GRAD_CH - 1) / GP_GRAD_CH : 1;
+    HIPCHK(hipMemcpyAsync(host.data(), g->dScal + 64, sizeof(double) * GP_GRAD_NACC * npass, hipMemcpyDeviceToHost,
+                          g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    (void)ntile;
+    *dvariance = host[0] / g->kp.variance;  // stationary.py:224
+    *dnoise = host[1];                      // gaussian.py:78-79
+    if (g->ard) {
+        for (int d = 0; d < D; ++d)         // -sum tmp (dx_q)^2 / l_q^3, stationary.py:230-235,260-261
+            dlengthscale[d] = -host[(d / GP_GRAD_CH) * GP_GRAD_NACC + 2 + (d % GP_GRAD_CH)] / g->kp.ls[d];
+    } else {
+        dlengthscale[0] = -host[2] / g->kp.ls[0];  // -sum(dL_dr * r) / l, stationary.py:237-238
+    }
+    return 0;
+}
+
+// ---- second candidate-sized buffer (beta = K(Xs,X) Ky^-1, or the full covariance) -----------------
+static int ensure_grad_buffers(gp_ctx *g, long elemsT2, long M) {
+    int rc;
+    if ((rc = dev_realloc(&g->dT2, &g->capT2, elemsT2))) return rc;
+    const long need = M * (long)g->D * std::max(1, g->P);
+    if (!g->dDm || g->capD < need) {
+        for (double **b : {&g->dDm, &g->dDv, &g->dDacq}) {
+            if (*b) hipFree(*b);
+            *b = nullptr;
+        }
+        HIPCHK(hipMalloc((void **)&g->dDm, sizeof(double) * need));
+        HIPCHK(hipMalloc((void **)&g->dDv, sizeof(double) * need));
+        HIPCHK(hipMalloc((void **)&g->dDacq, sizeof(double) * need));
+        g->capD = need;
+    }
+    return 0;
+}
+
+// predictive gradients of all resident candidates into dDm [M, D, P] and dDv [M, D]
+static int run_predict_grad(gp_ctx *g) {
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    int rc;
+    if ((rc = ensure_wi(g))) return rc;
+    const long M = g->M, N = g->N, Npad = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    const long mc_max = std::min(g->mc_max, round_up(M, GP_TILE));
+    if ((rc = dev_realloc(&g->dT, &g->capT, std::max(g->capT, mc_max * Npad)))) return rc;
+    if ((rc = ensure_grad_buffers(g, mc_max * Npad, M))) return rc;
+    for (long m0 = 0; m0 < M; m0 += mc_max) {
+        const long mc = std::min(mc_max, M - m0);
+        const long mcpad = round_up(mc, GP_TILE);
+        const int mt = (int)(mcpad / GP_TILE);
+        launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, N, Npad, g->kp);
+        // beta = K(Xs, X) Ky^-1   (gp.py:451-452; Ky^-1 symmetric => rows of Wi serve as the B operand)
+        gemm(g, g->s, 0, g->dT2, Npad, g->dT, Npad, g->dWi, Npad, 1, (int)Npad, TileSet{0, mt, 0, nt, 0});
+        launch_predict_grad(g->s, g->dXs + m0 * g->D, mc, g->dX, N, g->kp, g->dAlpha, Npad, g->P, g->dT2, Npad,
+                            g->dDm + m0 * g->D * g->P, g->dDv + m0 * g->D);
+    }
+    g->predicted = false;  // dT no longer holds the solved candidates
+    return 0;
+}
+
+int gp_predict_grad(gp_t *g, double *dmdx, double *dvdx) {
+    if (!g || !dmdx || !dvdx) return fail(GP_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = run_predict_grad(g))) return rc;
+    HIPCHK(hipMemcpyAsync(dmdx, g->dDm, sizeof(double) * g->M * g->D * g->P, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipMemcpyAsync(dvdx, g->dDv, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    return 0;
+}
+
+int gp_acq_grad(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, double *out, double *dout) {
+    if (!g || !out || !dout) return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    if (g->P != 1) return fail(GP_ERR_ARG, "acquisitions need P == 1");
+    if (type < GP_ACQ_EI || type > GP_ACQ_MPI) return fail(GP_ERR_ARG, "unknown acquisition %d", type);
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = ensure_out(g))) return rc;
+    if ((rc = run_predict_grad(g))) return rc;
+    if ((rc = run_predict(g, 1))) return rc;
+    launch_acq_grad(g->s, type, par, fmin, y_mean, y_std, g->dMean, g->dVar, g->dDm, g->dDv, g->M, g->D, g->dAcq,
+                    g->dDacq);
+    HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipMemcpyAsync(dout, g->dDacq, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    return 0;
+}
+
+// full_cov = True branch of PosteriorExact._raw_predict (posterior.py:280-284)
+int gp_predict_full_cov(gp_t *g, int include_noise, double *mean, double *cov) {
+    if (!g || !cov) return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    HIPCHK(hipSetDevice(g->device));
+    const long M = g->M, Npad = g->Npad, Mpad = round_up(M, GP_TILE);
+    if (Mpad > g->mc_max) return fail(GP_ERR_ARG, "full covariance needs M <= mc_max (%ld)", g->mc_max);
+    int rc;
+    if ((rc = ensure_out(g))) return rc;
+    if ((rc = run_predict(g, include_noise))) return rc;  // leaves T = K(Xs,X) L^-T in dT (single chunk)
+    if ((rc = dev_realloc(&g->dT2, &g->capT2, std::max(g->capT2, Mpad * Mpad)))) return rc;
+    const int mt = (int)(Mpad / GP_TILE);
+    launch_kbuild(g->s, g->dT2, Mpad, g->dXs, M, Mpad, g->kp, 0.0, 1);  // K(Xs, Xs)
+    gemm(g, g->s, 1, g->dT2, Mpad, g->dT, Npad, g->dT, Npad, 1, (int)Npad, TileSet{0, mt, 0, mt, 0});
+    if (include_noise) launch_add_diag(g->s, g->dT2, Mpad, M, g->noise);  // gaussian.py:104-105
+    if (mean) HIPCHK(hipMemcpyAsync(mean, g->dMean, sizeof(double) * M * g->P, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    HIPCHK(hipMemcpy2D(cov, sizeof(double) * M, g->dT2, sizeof(double) * Mpad, sizeof(double) * M, M,
+                       hipMemcpyDeviceToHost));
+    return 0;
 }
 
 }  // extern "C"
 
-__global__ void add_diag_kernel(double *A, long lda, long N, double v) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) A[i * lda + i] += v;
-}
-void launch_add_diag(hipStream_t s, double *A, long lda, long N, double v) {
-    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, A, lda, N, v);
-}

@@ -16,7 +16,7 @@
 //
 // Work decomposition: 256 threads = 4 waves as 2x2; each wave owns a 64x64 sub-tile =
 // 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  Per BK stage a wave issues 64 MFMAs
-// against 32 ds_read_b64, i.e. the matrix pipe is the only busy unit; the next stage's global
+// against 16 ds_read_b128, i.e. the matrix pipe is the only busy unit; the next stage's global
 // loads are issued before the MFMAs and written to the other LDS buffer after them (one
 // barrier per stage).  Two workgroups per CU (73.7 KB LDS each, <=256 VGPRs) keep a second
 // wave per SIMD ready while the first sits at the barrier or in the C epilogue.
@@ -37,6 +37,7 @@ struct GemmArgs {
     int b_mul;
     int K;
     int r0, r1, c0, c1, tri;
+    int k_tri;  // contraction starts at column ti*128 (A is block upper-triangular: lauum-type products)
 };
 
 __device__ __forceinline__ void tile_from_linear(long t, const GemmArgs &a, int &i, int &c) {
@@ -82,8 +83,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
 
-    const double *Ag = a.A + (long)ti * GP_TILE * a.lda;
-    const double *Bg = a.B + (long)tc * a.b_mul * GP_TILE * a.ldb;
+    const int kstart = a.k_tri ? ti * GP_TILE : 0;
+    const double *Ag = a.A + (long)ti * GP_TILE * a.lda + kstart;
+    const double *Bg = a.B + (long)tc * a.b_mul * GP_TILE * a.ldb + kstart;
 
     // staging map: 128 rows x 8 chunks(16 B); thread handles rows (tid>>3) + 32q, chunk tid&7
     const int srow = tid >> 3, sch = (tid & 7) * 2;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
         for (int n = 0; n < 4; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     double2_t ra[4], rb[4];
-    const int nk = a.K / BK;
+    const int nk = (a.K - kstart) / BK;
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -180,13 +182,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
 }
 
 void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *A, long lda,
-                    const double *B, long ldb, int b_mul, int K, TileSet ts) {
+                    const double *B, long ldb, int b_mul, int K, TileSet ts, int k_tri) {
     long n = tileset_count(ts);
     if (n <= 0 || K <= 0) return;
     GemmArgs a;
     a.C = C; a.ldc = ldc; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
     a.b_mul = b_mul; a.K = K;
     a.r0 = ts.r0; a.r1 = ts.r1; a.c0 = ts.c0; a.c1 = ts.c1; a.tri = ts.tri;
+    a.k_tri = k_tri;
     if (mode == 0)
         hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)n), dim3(256), 0, s, a);
     else

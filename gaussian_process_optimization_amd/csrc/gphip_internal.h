@@ -37,7 +37,7 @@ static inline long tileset_count(const TileSet &t) {
 // B rows   at B + (c*b_mul)*128*ldb    (K columns)
 // mode 0: C = A B^T ; mode 1: C -= A B^T
 void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *A, long lda,
-                    const double *B, long ldb, int b_mul, int K, TileSet ts);
+                    const double *B, long ldb, int b_mul, int K, TileSet ts, int k_tri = 0);
 
 // Factor the 128x128 diagonal tile t of A (row-major, lda) in place (lower) and write
 // its inverse (row-major 128x128, lower, zero above) to invL + t*128*128.
@@ -79,3 +79,19 @@ void launch_acq(hipStream_t s, int type, double par, double fmin, double y_mean,
                 const double *mean, const double *var, long M, double *out);
 void launch_argbest(hipStream_t s, const double *v, long n, int sense, double *best_val, long long *best_idx,
                     double *scratch_val, long long *scratch_idx);
+
+// ---- grad.hip ---------------------------------------------------------------------------------
+#define GP_GRAD_CH 16
+#define GP_GRAD_NACC (GP_GRAD_CH + 2)
+void launch_set_identity(hipStream_t s, double *T, long ld, long n);
+void launch_symmetrize(hipStream_t s, double *A, long ld, long n);
+void launch_lml_grad(hipStream_t s, const double *X, long N, long Npad, const KernParams &kp, int ard, int d0,
+                     const double *alpha, int P, const double *Wi, long ldw, double *partial, double *out);
+void launch_predict_grad(hipStream_t s, const double *Xs, long M, const double *X, long N, const KernParams &kp,
+                         const double *alpha, long lda_, int P, const double *beta, long ldb, double *dmdx,
+                         double *dvdx);
+void launch_acq_grad(hipStream_t s, int type, double par, double fmin, double y_mean, double y_std, const double *mean,
+                     const double *var, const double *dmdx, const double *dvdx, long M, int D, double *out,
+                     double *dout);
+void launch_add_diag(hipStream_t s, double *A, long lda, long N, double v);
+void launch_trace(hipStream_t s, const double *A, long lda, long N, double *out);

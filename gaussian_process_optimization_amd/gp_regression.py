@@ -1,0 +1,318 @@
+"""``GPRegression`` -- host mirror of ``GPy.models.GPRegression`` backed by libgphip.
+
+Reference: GPy/GPy/models/gp_regression.py:29-36 (constructor), GPy/GPy/core/gp.py
+(GP.__init__ :38-110, set_XY :202-238, parameters_changed :258-271, log_likelihood
+:273-277, predict :297-354, predict_noiseless :356-379, predictive_gradients :407-454,
+optimize :643-664), GPy/GPy/likelihoods/gaussian.py (variance :43, predictive_values
+:102-110), GPy/GPy/util/normalizer.py:85-108 (Standardize).
+
+All numerics (K build, Cholesky, solves, LML, gradients, posterior) run on the
+GPU through the C-ABI; this module is bookkeeping: hyper-parameters, the Y
+normaliser, lazy re-fit on parameter change, and the L-BFGS driver.
+"""
+import numpy as np
+from scipy import optimize as _sopt
+
+from . import _lib
+from .kern import RBF, Stationary
+from .parameterization import Param, Parameterized
+
+
+class Gaussian(Parameterized):
+    """GPy.likelihoods.Gaussian: one positive ``variance`` parameter (gaussian.py:31-47)."""
+
+    def __init__(self, variance=1., name="Gaussian_noise"):
+        super(Gaussian, self).__init__(name)
+        self.variance = Param("variance", np.atleast_1d(float(variance)))
+        self.link_parameter(self.variance)
+
+    def gaussian_variance(self, Y_metadata=None):
+        return self.variance  # gaussian.py:69-70
+
+
+class Standardize(object):
+    """GPy/GPy/util/normalizer.py:85-108."""
+
+    def __init__(self):
+        self.mean = None
+
+    def scale_by(self, Y):
+        Y = np.ma.masked_invalid(Y, copy=False)
+        self.mean = Y.mean(0).view(np.ndarray)
+        self.std = Y.std(0).view(np.ndarray)
+
+    def normalize(self, Y):
+        if not self.scaled():
+            raise AttributeError("Norm object not initialized yet, try calling scale_by(data) first.")
+        return (Y - self.mean) / self.std
+
+    def inverse_mean(self, X):
+        return (X * self.std) + self.mean
+
+    def inverse_variance(self, var):
+        return var * (self.std ** 2)
+
+    def inverse_covariance(self, covariance):
+        return covariance[..., np.newaxis] * (self.std ** 2)
+
+    def scaled(self):
+        return self.mean is not None
+
+
+class _PosteriorView(object):
+    """Read-only stand-in for GPy's Posterior object (posterior.py:9-270): the fields gp.py uses."""
+
+    def __init__(self, model):
+        self._m = model
+
+    @property
+    def woodbury_vector(self):
+        self._m._ensure_fit()
+        return self._m._h.alpha()
+
+    @property
+    def woodbury_chol(self):
+        self._m._ensure_fit()
+        return self._m._h.chol()
+
+    @property
+    def woodbury_inv(self):
+        self._m._ensure_fit()
+        return self._m._h.woodbury_inv()
+
+
+class GPRegression(Parameterized):
+    """Gaussian Process model for regression with a Gaussian likelihood, on one MI355X.
+
+    :param X: input observations [N, D]
+    :param Y: observed values [N, P]
+    :param kernel: ``kern.RBF`` / ``kern.Matern52`` (defaults to RBF, gp_regression.py:31-32)
+    :param normalizer: ``True`` standardises Y (gp.py:73-84)
+    :param noise_var: Gaussian noise variance (default 1)
+    :param device: HIP device ordinal
+    """
+
+    def __init__(self, X, Y, kernel=None, Y_metadata=None, normalizer=None, noise_var=1., mean_function=None,
+                 device=0, name="GP regression"):
+        super(GPRegression, self).__init__(name)
+        if mean_function is not None:
+            raise NotImplementedError("mean functions are outside the accelerated path")
+        X = np.asarray(X, dtype=float)
+        if kernel is None:
+            kernel = RBF(X.shape[1])
+        if not isinstance(kernel, Stationary):
+            raise TypeError("kernel must be kern.RBF or kern.Matern52")
+        self.kern = kernel
+        self.likelihood = Gaussian(variance=noise_var)
+        self.Gaussian_noise = self.likelihood
+        self.link_parameters(self.kern, self.likelihood)
+        if normalizer is True:
+            self.normalizer = Standardize()
+        elif normalizer in (False, None):
+            self.normalizer = None
+        else:
+            self.normalizer = normalizer
+        self.Y_metadata = Y_metadata
+        self.max_jitter_tries = 5  # jitchol default, linalg.py:56
+        self._h = _lib.Handle(device)
+        self._dirty = True
+        self._lml = None
+        self._jitter = 0.0
+        self.posterior = _PosteriorView(self)
+        self.set_XY(X, Y)
+
+    # -- data -------------------------------------------------------------------------
+    def set_XY(self, X=None, Y=None):
+        """GP.set_XY, gp.py:202-238."""
+        if Y is not None:
+            Y = np.asarray(Y, dtype=float)
+            if Y.ndim == 1:
+                Y = Y[:, None]
+            if self.normalizer is not None:
+                self.normalizer.scale_by(Y)
+                self.Y_normalized = self.normalizer.normalize(Y)
+            else:
+                self.Y_normalized = Y
+            self.Y = Y
+        if X is not None:
+            X = np.asarray(X, dtype=float)
+            assert X.ndim == 2
+            self.X = X
+        assert self.X.shape[0] == self.Y.shape[0]
+        assert self.X.shape[1] == self.kern.input_dim
+        self.num_data, self.input_dim = self.X.shape
+        self.output_dim = self.Y.shape[1]
+        self._h.set_data(self.X, self.Y_normalized)
+        self._dirty = True
+
+    def set_X(self, X):
+        self.set_XY(X=X)
+
+    def set_Y(self, Y):
+        self.set_XY(Y=Y)
+
+    # -- (re)fit ----------------------------------------------------------------------
+    def _on_change(self):
+        self._dirty = True
+
+    def _ensure_fit(self):
+        """GP.parameters_changed, gp.py:258-271: inference on the device when anything changed."""
+        if not self._dirty:
+            return
+        k = self.kern
+        self._h.set_params(k._kernel_id, k.ARD, float(k.variance), k.lengthscale.values,
+                           float(self.likelihood.variance))
+        self._lml, self._logdet, self._jitter = self._h.fit(self.max_jitter_tries)
+        self._dirty = False
+
+    def parameters_changed(self):
+        self._dirty = True
+        self._ensure_fit()
+
+    def log_likelihood(self):
+        """gp.py:273-277."""
+        self._ensure_fit()
+        return self._lml
+
+    def objective_function(self):
+        """Model.objective_function, core/model.py:96-110 (no priors on this path)."""
+        return -float(self.log_likelihood())
+
+    def _log_likelihood_gradients_natural(self):
+        self._ensure_fit()
+        nls = self.kern.lengthscale.size
+        dv, dl, dn = self._h.lml_grad(nls)
+        self.kern.variance.gradient = np.atleast_1d(dv)
+        self.kern.lengthscale.gradient = dl
+        self.likelihood.variance.gradient = np.atleast_1d(dn)
+        return [(self.kern.variance, dv), (self.kern.lengthscale, dl), (self.likelihood.variance, dn)]
+
+    def objective_function_gradients(self):
+        """Model.objective_function_gradients, core/model.py:112-127: d(-lml)/d(optimizer_array)."""
+        return -self._transform_gradients(self._log_likelihood_gradients_natural())
+
+    @property
+    def gradient(self):
+        g = self._log_likelihood_gradients_natural()
+        return np.concatenate([np.atleast_1d(np.asarray(x, dtype=float)).reshape(-1) for _, x in g])
+
+    # -- prediction ---------------------------------------------------------------------
+    def _stage(self, Xnew):
+        Xnew = np.asarray(Xnew, dtype=float)
+        if Xnew.ndim == 1:
+            Xnew = Xnew[None, :]
+        self._ensure_fit()
+        self._h.set_candidates(Xnew)
+        return Xnew
+
+    def _raw_predict(self, Xnew, full_cov=False, kern=None):
+        """gp.py:279-295 -> PosteriorExact._raw_predict (posterior.py:273-302)."""
+        if kern is not None and kern is not self.kern:
+            raise NotImplementedError("prediction with a foreign kernel is outside the accelerated path")
+        self._stage(Xnew)
+        if full_cov:
+            return self._h.predict_full_cov(include_noise=False)
+        return self._h.predict(include_noise=False)
+
+    def predict(self, Xnew, full_cov=False, Y_metadata=None, kern=None, likelihood=None, include_likelihood=True):
+        """gp.py:297-354."""
+        if kern is not None and kern is not self.kern:
+            raise NotImplementedError("prediction with a foreign kernel is outside the accelerated path")
+        self._stage(Xnew)
+        if full_cov:
+            mean, var = self._h.predict_full_cov(include_noise=include_likelihood)
+        else:
+            mean, var = self._h.predict(include_noise=include_likelihood)
+        if self.normalizer is not None:
+            mean = self.normalizer.inverse_mean(mean)
+            if full_cov and mean.shape[1] > 1:
+                var = self.normalizer.inverse_covariance(var)
+            else:
+                var = self.normalizer.inverse_variance(var)
+        return mean, var
+
+    def predict_noiseless(self, Xnew, full_cov=False, Y_metadata=None, kern=None):
+        """gp.py:356-379."""
+        return self.predict(Xnew, full_cov, Y_metadata, kern, None, False)
+
+    def predictive_gradients(self, Xnew, kern=None):
+        """gp.py:407-454: (dmu_dX [M, D, P], dv_dX [M, D])."""
+        self._stage(Xnew)
+        return self._h.predict_grad()
+
+    def posterior_samples_f(self, X, size=10, **kw):
+        """gp.py:581-609 (host-side draw from the device-computed full covariance)."""
+        m, v = self._raw_predict(X, full_cov=True)
+        if self.normalizer is not None:
+            m, v = self.normalizer.inverse_mean(m), self.normalizer.inverse_variance(v)
+        fsim = np.empty((X.shape[0], self.output_dim, size))
+        for d in range(self.output_dim):
+            fsim[:, d, :] = np.random.multivariate_normal(m[:, d], v, size).T
+        return fsim
+
+    # -- optimisation -------------------------------------------------------------------
+    def _obj_grad(self, x):
+        try:
+            self.optimizer_array = x
+            f = self.objective_function()
+            g = self.objective_function_gradients()
+        except np.linalg.LinAlgError:
+            return 1e10, np.zeros_like(x)  # paramz Model._objective_grads: failed evaluations are walls
+        return f, g
+
+    def optimize(self, optimizer=None, start=None, messages=False, max_iters=1000, ipython_notebook=False,
+                 clear_after_finish=False, **kwargs):
+        """GP.optimize (gp.py:643-664) -> scipy L-BFGS-B over the transformed parameters."""
+        if optimizer not in (None, "lbfgs", "lbfgsb", "bfgs", "scg"):
+            raise ValueError("unknown optimizer %r" % optimizer)
+        x0 = self.optimizer_array if start is None else np.asarray(start, dtype=float)
+        if x0.size == 0:
+            return None
+        res = _sopt.fmin_l_bfgs_b(self._obj_grad, x0, maxiter=int(max_iters), maxfun=int(max_iters) * 2)
+        xbest = res[0]
+        self.optimizer_array = xbest
+        self._ensure_fit()
+        return res
+
+    def randomize(self):
+        """paramz Parameterized.randomize: N(0,1) draws in the optimiser space."""
+        x = np.random.normal(size=self.optimizer_array.size)
+        self.optimizer_array = x
+
+    def optimize_restarts(self, num_restarts=10, robust=False, verbose=True, parallel=False, num_processes=None,
+                          **kwargs):
+        """paramz Model.optimize_restarts: keep the best of ``num_restarts`` L-BFGS runs."""
+        initial = self.optimizer_array.copy()
+        runs = []
+        for i in range(num_restarts):
+            try:
+                if i > 0:
+                    self.randomize()
+                self.optimize(**kwargs)
+                runs.append((self.objective_function(), self.optimizer_array.copy()))
+                if verbose:
+                    print("Optimization restart %d/%d, f = %s" % (i + 1, num_restarts, runs[-1][0]))
+            except Exception as e:  # noqa: BLE001  (robust mode of the reference swallows failures)
+                if robust:
+                    if verbose:
+                        print("Warning - optimization restart %d/%d failed: %s" % (i + 1, num_restarts, e))
+                else:
+                    raise
+        if runs:
+            best = min(runs, key=lambda t: t[0])
+            self.optimizer_array = best[1]
+        else:
+            self.optimizer_array = initial
+        self._ensure_fit()
+        return runs
+
+    # -- misc ---------------------------------------------------------------------------
+    def __str__(self):
+        self_lml = "?" if self._dirty else "%.6f" % self._lml
+        rows = ["Name : %s" % self.name, "Objective : -%s" % self_lml]
+        for p in self.flattened_parameters():
+            rows.append("  %s" % p)
+        return "\n".join(rows)
+
+    def close(self):
+        self._h.close()

@@ -1,0 +1,81 @@
+"""Host-side kernel descriptors mirroring ``GPy.kern.RBF`` / ``GPy.kern.Matern52``.
+
+Reference: GPy/GPy/kern/src/stationary.py:23-82 (Stationary.__init__: variance,
+lengthscale, ARD), rbf.py:12-57 (RBF), stationary.py:546-579 (Matern52).  These
+objects only *hold* hyper-parameters; every covariance evaluation happens on
+the GPU inside libgphip (kbuild.hip).  ``K``/``Kdiag`` are provided for API
+parity and run through the device as well.
+"""
+import numpy as np
+
+from . import _lib
+from .parameterization import Param, Parameterized
+
+
+class Stationary(Parameterized):
+    _kernel_id = None
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="stationary"):
+        super(Stationary, self).__init__(name)
+        self.input_dim = int(input_dim)
+        if active_dims is not None and list(active_dims) != list(range(self.input_dim)):
+            raise NotImplementedError("active_dims slicing is outside the accelerated path")
+        self.ARD = bool(ARD)
+        # stationary.py:66-79
+        if not ARD:
+            if lengthscale is None:
+                lengthscale = np.ones(1)
+            else:
+                lengthscale = np.asarray(lengthscale, dtype=float).reshape(-1)
+                assert lengthscale.size == 1, "Only 1 lengthscale needed for non-ARD kernel"
+        else:
+            if lengthscale is not None:
+                lengthscale = np.asarray(lengthscale, dtype=float).reshape(-1)
+                assert lengthscale.size in [1, input_dim], "Bad number of lengthscales"
+                if lengthscale.size != input_dim:
+                    lengthscale = np.ones(input_dim) * lengthscale
+            else:
+                lengthscale = np.ones(self.input_dim)
+        self.variance = Param("variance", np.atleast_1d(float(variance)))
+        self.lengthscale = Param("lengthscale", lengthscale)
+        assert self.variance.size == 1
+        self.link_parameters(self.variance, self.lengthscale)
+
+    # -- device-backed evaluations (API parity; not used by the fit/predict path) ------
+    def K(self, X, X2=None):
+        """kern.K(X[, X2]) -- stationary.py:107-140, evaluated by the K-build kernels."""
+        h = _lib.Handle(0)
+        try:
+            X = _lib.as_f64(X, 2)
+            if X2 is None:
+                h.set_data(X, np.zeros((X.shape[0], 1)))
+                h.set_params(self._kernel_id, self.ARD, float(self.variance), self.lengthscale.values, 0.0)
+                return h.kernel_matrix()
+            # cross covariance through the candidate path: K(X2 as candidates, X as data)^T
+            raise NotImplementedError("use GPRegression.predict for cross covariances")
+        finally:
+            h.close()
+
+    def Kdiag(self, X):
+        ret = np.empty(X.shape[0])  # stationary.py:195-198
+        ret[:] = float(self.variance)
+        return ret
+
+    def copy(self):
+        return self.__class__(self.input_dim, float(self.variance), self.lengthscale.values.copy(), self.ARD)
+
+
+class RBF(Stationary):
+    """GPy.kern.RBF -- k(r) = variance * exp(-r^2 / 2)  (rbf.py:50-51)."""
+    _kernel_id = _lib.GP_KERNEL_RBF
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="rbf"):
+        super(RBF, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name)
+
+
+class Matern52(Stationary):
+    """GPy.kern.Matern52 -- k(r) = variance (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)  (stationary.py:575-576)."""
+    _kernel_id = _lib.GP_KERNEL_MATERN52
+
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="Mat52"):
+        super(Matern52, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name)

@@ -1,0 +1,87 @@
+"""Candidate-table sharding over the GPUs of one node (one process per GPU).
+
+The acquisition batch of the reference (``acquisition_function(configurations)`` then
+``np.argmax`` / ``argsort``, run.py:1240-1241, anchor_points_generator.py:59-61) has no
+cross-candidate term (posterior.py:276-295 with full_cov=False), so the candidate rows are
+split into contiguous blocks, one per rank; every rank holds a replica of the fitted model
+(redundant fit, or one RCCL broadcast of L via gp_comm_bcast_fit), scores its block on its
+GPU, reduces a local (best value, global row) pair, and ONE collective -- an all-gather of
+16 bytes per rank over xGMI (RCCL inside libgphip, gp_comm_allgather_best) -- lets every rank
+take the global best with NumPy's lowest-index tie rule.
+
+``merge_best`` is the pure host part of that step; the collective itself is pluggable so the
+N > 1 logic is covered by world_size-2 gloo tests on CPU (tests/test_sharded_gloo.py).
+"""
+import numpy as np
+
+
+def shard_bounds(M, rank, nranks):
+    """Contiguous row block [lo, hi) of rank ``rank`` (first M % nranks ranks get one extra row)."""
+    base, rem = divmod(int(M), int(nranks))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def merge_best(vals, idxs, sense):
+    """Global best of per-rank (value, global index) pairs; ties -> lowest index (np.argmax/argmin).
+
+    Ranks with an empty shard contribute idx < 0 and are ignored.
+    """
+    vals = np.asarray(vals, dtype=float)
+    idxs = np.asarray(idxs, dtype=np.int64)
+    ok = idxs >= 0
+    if not ok.any():
+        raise ValueError("no rank produced a candidate")
+    v, i = vals[ok], idxs[ok]
+    best = v.max() if sense > 0 else v.min()
+    return int(i[v == best].min()), float(best)
+
+
+class RcclCollective(object):
+    """All-gather of (val, idx) through libgphip's RCCL communicator (GPU ranks)."""
+
+    def __init__(self, handle, nranks):
+        self.h, self.nranks = handle, nranks
+
+    def allgather_best(self, val, idx):
+        return self.h.comm_allgather_best(val, idx, self.nranks)
+
+
+class TorchCollective(object):
+    """Same exchange over ``torch.distributed`` (gloo on CPU for tests; plumbing only)."""
+
+    def __init__(self, nranks):
+        self.nranks = nranks
+
+    def allgather_best(self, val, idx):
+        import torch
+        import torch.distributed as dist
+        v = torch.tensor([float(val)], dtype=torch.float64)
+        i = torch.tensor([int(idx)], dtype=torch.int64)
+        vs = [torch.zeros(1, dtype=torch.float64) for _ in range(self.nranks)]
+        is_ = [torch.zeros(1, dtype=torch.int64) for _ in range(self.nranks)]
+        dist.all_gather(vs, v)
+        dist.all_gather(is_, i)
+        return np.array([t.item() for t in vs]), np.array([t.item() for t in is_], dtype=np.int64)
+
+
+class ShardedCandidates(object):
+    """Scores this rank's block of a candidate table and agrees on the global best.
+
+    ``score_local(Xblock, sense) -> (local_idx, value)`` is the device call
+    (``Acquisition*.argbest`` on the HIP path); ``collective`` is one of the classes above.
+    """
+
+    def __init__(self, rank, nranks, collective):
+        self.rank, self.nranks, self.collective = int(rank), int(nranks), collective
+
+    def argbest(self, X_all, score_local, sense=-1):
+        lo, hi = shard_bounds(X_all.shape[0], self.rank, self.nranks)
+        if hi > lo:
+            li, val = score_local(X_all[lo:hi], sense)
+            gi = lo + int(li)
+        else:
+            gi, val = -1, (-np.inf if sense > 0 else np.inf)
+        vals, idxs = self.collective.allgather_best(val, gi)
+        return merge_best(vals, idxs, sense)

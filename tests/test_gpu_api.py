@@ -1,0 +1,176 @@
+"""GPU: the host mirror of the reference API (GPRegression / GPModel / Acquisition* / BayesianOptimization).
+
+These follow the reference's own tests for the path: pinv closed form
+(GPy/GPy/testing/model_tests.py:63-82), var >= 0 stress (:25-61), normaliser equivalence (:84-119),
+checkgrad-style finite differences (:664-723, kernel_tests.py:414-422), set_XY round trip
+(gp_tests.py:50-60).
+"""
+import numpy as np
+import pytest
+
+import gaussian_process_optimization_amd as gpo
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_raw_predict_pinv_closed_form():
+    rng = np.random.RandomState(0)
+    N, M = 20, 50
+    X = rng.randn(N, 1); Y = np.sin(X) + rng.randn(N, 1) * 0.05; Xn = rng.randn(M, 1)
+    k = gpo.kern.RBF(1)
+    m = gpo.models.GPRegression(X, Y, kernel=k, noise_var=0.5)
+    ko = O.RBF(1, 1.0, 1.0)
+    Kinv = np.linalg.pinv(ko.K(X) + np.eye(N) * 0.5)
+    mu_hat = ko.K(Xn, X).dot(Kinv).dot(Y)
+    cov_hat = ko.K(Xn) - ko.K(Xn, X).dot(Kinv).dot(ko.K(X, Xn))
+    mu, cov = m.predict_noiseless(Xn, full_cov=True)
+    assert mu.shape == (M, 1) and cov.shape == (M, M)
+    np.testing.assert_almost_equal(mu_hat, mu)
+    np.testing.assert_almost_equal(cov_hat, cov)
+    mu, var = m.predict_noiseless(Xn)
+    np.testing.assert_almost_equal(np.diag(cov_hat)[:, None], var)
+    m.close()
+
+
+def test_raw_predict_numerical_stability():
+    rs = np.random.RandomState(3)
+    x1, x2 = np.meshgrid(np.linspace(-5, 10, 5), np.linspace(0, 15, 5))
+    X = np.c_[x1.ravel(), x2.ravel()]
+    Y = ((X[:, 1] - 5.1 / (4 * np.pi ** 2) * X[:, 0] ** 2 + 5 * X[:, 0] / np.pi - 6) ** 2
+         + 10 * (1 - 1 / (8 * np.pi)) * np.cos(X[:, 0]) + 10)[:, None]
+    m = gpo.models.GPRegression(X, Y, gpo.kern.RBF(2, 2.0, [5.0, 5.0], ARD=True), noise_var=1e-5)
+    Xt = np.c_[rs.uniform(-5, 10, 100000), rs.uniform(0, 15, 100000)]
+    _, v = m.predict(Xt)
+    assert (v >= 0).all()
+    m.close()
+
+
+def test_normalizer_equivalence():
+    rng = np.random.RandomState(1)
+    X = rng.rand(30, 2); Y = rng.randn(30, 1) * 4 + 7
+    m1 = gpo.models.GPRegression(X, Y, gpo.kern.RBF(2, 1.0, 0.5), normalizer=True, noise_var=0.1)
+    Ys = (Y - Y.mean(0)) / Y.std(0)
+    m2 = gpo.models.GPRegression(X, Ys, gpo.kern.RBF(2, 1.0, 0.5), noise_var=0.1)
+    a, va = m1.predict(X[:7]); b, vb = m2.predict(X[:7])
+    np.testing.assert_allclose(a, b * Y.std(0) + Y.mean(0), rtol=1e-10)
+    np.testing.assert_allclose(va, vb * Y.std(0) ** 2, rtol=1e-10)
+    assert m1.log_likelihood() == m2.log_likelihood()
+    m1.close(); m2.close()
+
+
+@pytest.mark.parametrize("cls", ["RBF", "Matern52"])
+@pytest.mark.parametrize("ard", [False, True])
+def test_checkgrad(cls, ard):
+    rng = np.random.RandomState(2)
+    D = 2
+    X = rng.rand(40, D); Y = rng.randn(40, 1)
+    k = getattr(gpo.kern, cls)(D, 1.3, [0.4, 0.7] if ard else 0.5, ARD=ard)
+    m = gpo.models.GPRegression(X, Y, k, noise_var=0.2)
+    x0 = m.optimizer_array.copy()
+    g = m.objective_function_gradients()
+    for i in range(x0.size):
+        e = np.zeros_like(x0); e[i] = 1e-6
+        m.optimizer_array = x0 + e; fp = m.objective_function()
+        m.optimizer_array = x0 - e; fm = m.objective_function()
+        assert abs((fp - fm) / 2e-6 - g[i]) <= 1e-5 * max(1.0, abs(g[i]))
+    m.optimizer_array = x0
+    xs = rng.rand(3, D)
+    dm, dv = m.predictive_gradients(xs)
+    assert dm.shape == (3, D, 1) and dv.shape == (3, D)
+    for q in range(D):
+        e = np.zeros((1, D)); e[0, q] = 1e-6
+        mp, vp = m.predict(xs + e); mm, vm = m.predict(xs - e)
+        np.testing.assert_allclose(dm[:, q, 0], ((mp - mm) / 2e-6)[:, 0], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(dv[:, q], ((vp - vm) / 2e-6)[:, 0], rtol=1e-4, atol=1e-6)
+    m.close()
+
+
+def test_setxy_roundtrip_and_optimize():
+    np.random.seed(12345)
+    X = np.random.rand(60, 2); Y = np.sin(3 * X[:, :1]) + 0.1 * np.random.randn(60, 1)
+    m = gpo.models.GPRegression(X, Y, gpo.kern.Matern52(2), noise_var=0.5)
+    l0 = m.log_likelihood()
+    m.set_XY(X[:30], Y[:30])
+    assert m.log_likelihood() != l0
+    m.set_XY(X, Y)
+    assert m.log_likelihood() == l0
+    m.optimize(max_iters=200)
+    assert m.log_likelihood() > l0 + 1.0
+    p = m.param_array.copy()
+    assert (p > 0).all()
+    runs = m.optimize_restarts(num_restarts=2, verbose=False, max_iters=50)
+    assert len(runs) == 2 and m.objective_function() <= min(r[0] for r in runs) + 1e-9
+    m.close()
+
+
+def _oracle_twin(X, Y, kname, ls, var, noise):
+    gp = O.OracleGP(X, Y, O.make_kernel(kname, X.shape[1], var, ls, ARD=np.size(ls) > 1), noise)
+    return gp, O.OracleGPModel(gp)
+
+
+def test_gpmodel_and_acquisitions_match_reference_formulas():
+    X, Y, Xs = O.synthetic_problem(150, 3, 400, seed=21)
+    gm = gpo.GPModel(kernel=gpo.kern.Matern52(3, 1.2, 0.6), noise_var=0.03, max_iters=0, verbose=False)
+    gm.updateModel(X, Y, None, None)
+    gp0, gm0 = _oracle_twin(X, Y, "Mat52", [0.6], 1.2, 0.03)
+    # GPModel defaults put a bounded constraint on the noise: value unchanged
+    assert float(gm.model.Gaussian_noise.variance) == pytest.approx(0.03, rel=1e-12)
+    m, s = gm.predict(Xs); m0, s0 = gm0.predict(Xs)
+    np.testing.assert_allclose(m, m0, rtol=1e-6, atol=1e-9); np.testing.assert_allclose(s, s0, rtol=1e-6)
+    assert gm.get_fmin() == pytest.approx(gm0.get_fmin(), rel=1e-6)
+    mm, ss, dm, ds = gm.predict_withGradients(Xs[:20]); r = gm0.predict_withGradients(Xs[:20])
+    for a, b in zip((mm, ss, dm, ds), r):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-8)
+    for cls, fn, fng, kw in ((gpo.AcquisitionEI, O.acq_EI, O.acq_EI_withGradients, dict(jitter=0.01)),
+                             (gpo.AcquisitionLCB, O.acq_LCB, O.acq_LCB_withGradients, dict(exploration_weight=2)),
+                             (gpo.AcquisitionMPI, O.acq_MPI, O.acq_MPI_withGradients, dict(jitter=0.01))):
+        acq = cls(gm, **kw)
+        par = list(kw.values())[0]
+        ref = -fn(gm0, Xs, par)
+        a = acq.acquisition_function(Xs)                    # device batched path
+        assert a.shape == (400, 1)
+        np.testing.assert_allclose(a, ref, rtol=1e-6, atol=1e-9 * np.max(np.abs(ref)))
+        host = -acq._compute_acq(Xs)                         # reference host formula on device predictions
+        np.testing.assert_allclose(host, ref, rtol=1e-6, atol=1e-9 * np.max(np.abs(ref)))
+        f, df = acq.acquisition_function_withGradients(Xs[:20])
+        f0, df0 = fng(gm0, Xs[:20], par)
+        np.testing.assert_allclose(f, -f0, rtol=1e-6, atol=1e-9 * np.max(np.abs(ref)))
+        np.testing.assert_allclose(df, -df0, rtol=1e-5, atol=1e-8 * np.max(np.abs(df0)))
+        i, v = acq.argbest(Xs, -1)
+        assert i == int(np.argmin(a)) and v == a[i, 0]
+        i, v = acq.argbest(Xs, +1)                           # run.py:1241 takes argmax of the same vector
+        assert i == int(np.argmax(a))
+    gm.model.close()
+
+
+def test_acquisition_with_normalizer_on_device():
+    X, Y, Xs = O.synthetic_problem(120, 2, 300, seed=5, standardize=False)
+    Y = 10 * Y + 3
+    gm = gpo.GPModel(kernel=gpo.kern.RBF(2, 1.0, 0.4), noise_var=0.05, max_iters=0, verbose=False)
+    gm.model = gpo.models.GPRegression(X, Y, gpo.kern.RBF(2, 1.0, 0.4), normalizer=True, noise_var=0.05)
+    gp0 = O.OracleGP(X, Y, O.RBF(2, 1.0, 0.4), 0.05, normalizer=True)
+    gm0 = O.OracleGPModel(gp0)
+    acq = gpo.AcquisitionEI(gm, jitter=0.01)
+    ref = -O.acq_EI(gm0, Xs, 0.01)
+    np.testing.assert_allclose(acq.acquisition_function(Xs), ref, rtol=1e-6, atol=1e-9 * np.max(np.abs(ref)))
+    gm.model.close()
+
+
+def test_bayesian_optimization_loop_improves():
+    np.random.seed(0)
+    f = lambda x: np.sum((x - 0.3) ** 2, axis=1, keepdims=True)  # noqa: E731
+    dom = [{'name': 'x', 'type': 'continuous', 'domain': (0, 1), 'dimensionality': 2}]
+    X0 = np.random.rand(6, 2)
+    bo = gpo.methods.BayesianOptimization(f=f, domain=dom, X=X0, Y=f(X0), acquisition_type='EI', exact_feval=True,
+                                          optimize_restarts=1, max_iters=100)
+    x1 = bo.suggest_next_locations()
+    assert x1.shape == (1, 2) and (x1 >= 0).all() and (x1 <= 1).all()
+    xo, fo = bo.run_optimization(max_iter=6)
+    assert fo <= f(X0).min() + 1e-12 and fo < 0.02
+    # user-table pattern of run.py:1240-1241: score a fixed candidate table, take the arg-best
+    table = np.random.rand(5000, 2)
+    vals = bo.acquisition.acquisition_function(table)
+    i, v = bo.acquisition.argbest(table, -1)
+    assert i == int(np.argmin(vals))
+    bo.model.model.close()

@@ -1,0 +1,235 @@
+"""GPU: parity of the HIP path (through the C-ABI) with the golden vectors and the live oracle.
+
+Tolerances (BASELINE.json:north_star): posterior mean / variance within 1e-6 relative, LML within
+1e-8 relative.  Bit-exactness is not expected: the Cholesky, the distance formula and every
+reduction run in a different (blocked / fused) order than LAPACK + NumPy.
+At noise 1e-6 (cond(Ky) ~ 1e8..1e9) solve-dependent quantities are compared at 1e-5.
+"""
+import numpy as np
+import pytest
+
+from conftest import Case, golden_tags, relmax
+from gaussian_process_optimization_amd import _lib
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _tags():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gp_golden.npz"))
+    return golden_tags(g)
+
+
+@pytest.fixture(scope="module")
+def h():
+    hd = _lib.Handle(0)
+    yield hd
+    hd.close()
+
+
+@pytest.mark.parametrize("tag", _tags())
+def test_golden_case(golden, h, tag):
+    c = Case(golden, tag)
+    noise = float(c.noise)
+    tol = 1e-6 if noise >= 1e-4 else 1e-5
+    h.set_data(c.X, c.Y)
+    h.set_params(int(c.kernel), int(c.ard), float(c.variance), c.lengthscale, noise)
+    K = h.kernel_matrix()
+    assert relmax(K[c.rows], c.K_rows) < 1e-13
+    assert np.allclose(K, K.T, rtol=0, atol=0)
+    lml, logdet, jit = h.fit()
+    assert jit == 0.0
+    assert abs(lml - float(c.lml)) <= 1e-8 * abs(float(c.lml))
+    assert abs(logdet - float(c.logdet)) <= 1e-10 * abs(float(c.logdet))
+    L = h.chol()
+    assert relmax(L[c.rows], c.L_rows) < tol
+    assert relmax(np.diag(L), c.L_diag) < tol
+    assert np.all(np.triu(L, 1) == 0)
+    assert relmax(h.alpha(), c.alpha) < tol
+    h.set_candidates(c.Xs)
+    mu, var = h.predict(True)
+    assert relmax(mu, c.mu) < tol
+    assert np.max(np.abs(var - c.var) / np.abs(c.var)) < tol
+    mu0, var0 = h.predict(False)
+    assert relmax(mu0, c.mu) < tol
+    assert np.max(np.abs(var0 - c.var_noiseless)) < tol * float(c.variance)
+    if "cov_full" in [k.split("/")[1] for k in golden.files if k.startswith(tag + "/")]:
+        _, cov = h.predict_full_cov(True)
+        assert relmax(cov, c.cov_full) < tol
+    # gradients of the LML (natural space)
+    dv, dl, dn = h.lml_grad(c.lengthscale.size)
+    gtol = 1e-6 if noise >= 1e-4 else 1e-4
+    scale = max(abs(float(c.dvariance)), np.max(np.abs(c.dlengthscale)), 1.0)
+    assert abs(dv - float(c.dvariance)) < gtol * scale
+    assert np.max(np.abs(dl - c.dlengthscale)) < gtol * scale
+    assert abs(dn - float(c.dnoise)) < gtol * max(abs(float(c.dnoise)), 1.0)
+    Wi = h.woodbury_inv()
+    assert relmax(Wi[c.rows], c.Wi_rows) < (1e-6 if noise >= 1e-4 else 1e-3)
+    assert np.array_equal(Wi, Wi.T)
+    # predictive gradients, fmin, acquisitions (+ gradients), arg-best
+    dm, dvx = h.predict_grad()
+    assert relmax(dm, c.dmdx) < tol
+    assert relmax(dvx, c.dvdx) < (1e-6 if noise >= 1e-4 else 1e-4)
+    fmin = h.fmin()
+    assert abs(fmin - float(c.fmin)) < tol * max(1.0, abs(float(c.fmin)))
+    f0 = float(c.fmin)
+    for t, par, name in ((_lib.GP_ACQ_EI, 0.01, "EI"), (_lib.GP_ACQ_LCB, 2.0, "LCB"), (_lib.GP_ACQ_MPI, 0.01, "MPI")):
+        ref = getattr(c, "neg_" + name)
+        a = h.acq(t, par, f0)
+        atol = tol * max(np.max(np.abs(ref)), 1e-30)
+        assert np.max(np.abs(a - ref)) <= atol
+        a2, da = h.acq_grad(t, par, f0)
+        assert np.max(np.abs(a2 - ref)) <= atol
+        dref = getattr(c, "neg_d" + name)
+        assert np.max(np.abs(da - dref)) <= (10 * tol) * max(np.max(np.abs(dref)), 1e-30)
+        idx, val = h.acq_argbest(t, par, f0, -1)
+        ia = int(np.argmin(a[:, 0]))
+        assert idx == ia and val == a[ia, 0]
+        # same winner as the reference unless the top two are closer than the tolerance
+        ir = int(getattr(c, "argmin_" + name))
+        assert idx == ir or abs(ref[idx, 0] - ref[ir, 0]) <= 2 * atol
+        idx2, val2 = h.acq_argbest(t, par, f0, +1)
+        assert idx2 == int(np.argmax(a[:, 0])) and val2 == a[idx2, 0]
+
+
+def test_multi_output_with_normalizer(golden):
+    import gaussian_process_optimization_amd as gpo
+    m = gpo.models.GPRegression(golden["multi/X"], golden["multi/Y"], gpo.kern.RBF(3, 0.9, [0.3, 0.5, 0.7], ARD=True),
+                                normalizer=True, noise_var=0.02)
+    mu, var = m.predict(golden["multi/Xs"])
+    assert relmax(mu, golden["multi/mu"]) < 1e-6
+    assert relmax(var, golden["multi/var"]) < 1e-6
+    assert abs(m.log_likelihood() - float(golden["multi/lml"])) <= 1e-8 * abs(float(golden["multi/lml"]))
+    assert relmax(m.posterior.woodbury_vector, golden["multi/alpha"]) < 1e-6
+    g = m.gradient
+    ref = np.r_[golden["multi/dvariance"], golden["multi/dlengthscale"], golden["multi/dnoise"]]
+    assert np.max(np.abs(g - ref)) < 1e-6 * np.max(np.abs(ref))
+    m.close()
+
+
+def test_jitter_ladder(golden, h):
+    """The reference's ladder (linalg.py:62-75): un-jittered dpotrf, then mean(diag)*1e-6 * 10^k."""
+    for name in ("jit1", "jit3"):
+        h.set_data(golden[name + "/X"], golden[name + "/Y"])
+        h.set_params(_lib.GP_KERNEL_RBF, 0, 1.0, [0.5], float(golden[name + "/noise"]))
+        lml, logdet, jit = h.fit(5)
+        assert jit == pytest.approx(float(golden[name + "/jitter"]), rel=1e-12)
+        assert logdet == pytest.approx(float(golden[name + "/logdet"]), rel=1e-4)
+    h.set_data(golden["jitfail/X"], golden["jitfail/Y"])
+    h.set_params(_lib.GP_KERNEL_RBF, 0, 1.0, [0.5], float(golden["jitfail/noise"]))
+    with pytest.raises(np.linalg.LinAlgError, match="even with jitter"):
+        h.fit(5)
+    # maxtries bounds the ladder (linalg_test.py:18-37: succeeds with enough tries, raises with fewer)
+    h.set_data(golden["jit3/X"], golden["jit3/Y"])
+    h.set_params(_lib.GP_KERNEL_RBF, 0, 1.0, [0.5], float(golden["jit3/noise"]))
+    with pytest.raises(np.linalg.LinAlgError):
+        h.fit(2)
+    h.fit(3)
+    # non-positive diagonal (linalg.py:63-64)
+    h.set_params(_lib.GP_KERNEL_RBF, 0, 1.0, [0.5], -2.0)
+    with pytest.raises(np.linalg.LinAlgError, match="non-positive diagonal"):
+        h.fit(5)
+
+
+@pytest.mark.parametrize("N,D,M,P", [(1, 1, 1, 1), (2, 3, 5, 1), (127, 2, 3, 2), (128, 2, 128, 1), (129, 4, 129, 1),
+                                     (700, 5, 257, 2), (300, 17, 40, 1), (1500, 3, 33, 1)])
+@pytest.mark.parametrize("kname", ["rbf", "Mat52"])
+def test_live_oracle_ragged_shapes(h, N, D, M, P, kname):
+    rng = np.random.default_rng(N * 31 + D)
+    X = rng.uniform(0, 1, (N, D))
+    Y = rng.standard_normal((N, P))
+    Xs = rng.uniform(-0.1, 1.1, (M, D))
+    ard = D > 1
+    ls = rng.uniform(0.3, 1.2, D) if ard else np.array([0.6])
+    kern = O.make_kernel(kname, D, 1.7, ls, ARD=ard)
+    gp = O.OracleGP(X, Y, kern, 0.05)
+    h.set_data(X, Y)
+    h.set_params(0 if kname == "rbf" else 1, ard, 1.7, ls, 0.05)
+    lml, logdet, jit = h.fit()
+    p = gp.posterior
+    assert abs(lml - p["lml"]) <= 1e-8 * max(1.0, abs(p["lml"]))
+    assert relmax(h.alpha(), p["alpha"]) < 1e-6
+    h.set_candidates(Xs)
+    mu, var = h.predict(True)
+    m0, v0 = gp.predict(Xs)
+    assert relmax(mu, m0) < 1e-6 and np.max(np.abs(var - v0) / np.abs(v0)) < 1e-6
+    dv, dl, dn = h.lml_grad(ls.size)
+    r = gp.gradients()
+    sc = max(1.0, abs(r[0]), np.max(np.abs(r[1])))
+    assert abs(dv - r[0]) < 1e-6 * sc and np.max(np.abs(dl - r[1])) < 1e-6 * sc and abs(dn - r[2]) < 1e-6 * max(1, abs(r[2]))
+    dm, dvx = h.predict_grad()
+    dm0, dv0 = gp.predictive_gradients(Xs)
+    assert np.max(np.abs(dm - dm0)) < 1e-6 * max(1.0, np.max(np.abs(dm0)))
+    assert np.max(np.abs(dvx - dv0)) < 1e-6 * max(1.0, np.max(np.abs(dv0)))
+
+
+def test_near_duplicate_rows_matern(h):
+    """Matern-5/2 depends on r, not r^2: near-duplicate inputs are where the reference's Gram-trick
+    distance is least accurate ('Distance formula')."""
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 1, (200, 3))
+    X[100:] = X[:100] + 1e-9 * rng.standard_normal((100, 3))
+    Y = np.sin(X.sum(1, keepdims=True))
+    kern = O.Matern52(3, 1.0, 0.5)
+    gp = O.OracleGP(X, Y, kern, 1e-2)
+    h.set_data(X, Y)
+    h.set_params(1, 0, 1.0, [0.5], 1e-2)
+    lml, _, _ = h.fit()
+    assert abs(lml - gp.log_likelihood()) <= 1e-8 * abs(gp.log_likelihood())
+    Xs = rng.uniform(0, 1, (50, 3))
+    h.set_candidates(Xs)
+    mu, var = h.predict(True)
+    m0, v0 = gp.predict(Xs)
+    assert relmax(mu, m0) < 1e-6 and np.max(np.abs(var - v0) / v0) < 1e-6
+
+
+def test_argbest_tie_breaks_to_lowest_index(h):
+    rng = np.random.default_rng(8)
+    X = rng.uniform(0, 1, (50, 2)); Y = rng.standard_normal((50, 1))
+    h.set_data(X, Y)
+    h.set_params(0, 0, 1.0, [0.4], 0.1)
+    h.fit()
+    Xs = rng.uniform(0, 1, (3000, 2))
+    Xs[2500] = Xs[7]; Xs[1200] = Xs[7]
+    h.set_candidates(Xs)
+    a = h.acq(_lib.GP_ACQ_LCB, 2.0, 0.0)[:, 0]
+    assert a[7] == a[1200] == a[2500]
+    # force the tie to be the winner by scoring only duplicates of row 7 plus worse points
+    worst = np.argsort(a)[-500:]
+    Xt = np.vstack([Xs[worst], Xs[[7]], Xs[worst[:5]], Xs[[7]]])
+    h.set_candidates(Xt)
+    at = h.acq(_lib.GP_ACQ_LCB, 2.0, 0.0)[:, 0]
+    for sense, fn in ((-1, np.argmin), (+1, np.argmax)):
+        idx, val = h.acq_argbest(_lib.GP_ACQ_LCB, 2.0, 0.0, sense)
+        assert idx == int(fn(at)) and val == at[idx]
+
+
+def test_refit_is_bitwise_reproducible(h):
+    X, Y, Xs = O.synthetic_problem(900, 4, 100, seed=9)
+    h.set_data(X, Y)
+    h.set_params(0, 0, 1.0, [0.5], 1e-2)
+    h.set_candidates(Xs)
+    r1 = (h.fit(), h.alpha(), h.predict(True))
+    r2 = (h.fit(), h.alpha(), h.predict(True))
+    assert r1[0] == r2[0] and np.array_equal(r1[1], r2[1])
+    assert np.array_equal(r1[2][0], r2[2][0]) and np.array_equal(r1[2][1], r2[2][1])
+    for pt in (1, 2, 3, 8):  # panel width is a schedule choice, not a numerical one (same tile arithmetic)
+        h.set_option("panel_tiles", pt)
+        lml = h.fit()[0]
+        assert abs(lml - r1[0][0]) <= 1e-11 * abs(r1[0][0])
+    h.set_option("panel_tiles", 4)
+
+
+def test_state_errors(h):
+    hd = _lib.Handle(0)
+    with pytest.raises(RuntimeError):
+        hd.fit()
+    hd.set_data(np.zeros((3, 2)), np.zeros((3, 1)))
+    with pytest.raises(RuntimeError):
+        hd.fit()
+    with pytest.raises(ValueError):
+        hd.set_params(7, 0, 1.0, [1.0], 0.1)
+    with pytest.raises(ValueError):
+        hd.set_data(np.zeros((3, 65)), np.zeros((3, 1)))
+    hd.close()

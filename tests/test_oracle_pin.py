@@ -1,0 +1,30 @@
+"""CPU (build container only): the oracle against the reference's verbatim leaf modules and compiled C."""
+import pytest
+
+from oracle import pin_against_reference as pin
+from oracle import ref_leaf
+
+needs_ref = pytest.mark.skipif(not ref_leaf.available(), reason="reference tree not mounted (GPU box)")
+
+
+@needs_ref
+def test_linalg_bit_identical():
+    assert "bit-identical" in pin.check_linalg(ref_leaf.load())
+
+
+@needs_ref
+def test_native_reductions():
+    lib = ref_leaf.load_stationary_utils()
+    if lib is None:
+        pytest.skip("oracle/_ref not built")
+    pin.check_native(lib)
+
+
+@needs_ref
+def test_lml_through_reference():
+    pin.check_lml_through_reference(ref_leaf.load())
+
+
+def test_reference_test_invariants():
+    # pinv closed form, var >= 0, normaliser equivalence, finite-difference gradients (no reference import needed)
+    pin.check_invariants()

@@ -57,6 +57,7 @@ SIGNATURES = [
                                       c_double_p]),
     ("gp_profile", ctypes.c_int, [_vp, ctypes.c_int]),
     ("gp_gemm_stats", ctypes.c_int, [_vp, c_int64_p, c_double_p, c_double_p]),
+    ("gp_gemm_trace", ctypes.c_int, [_vp, ctypes.c_int, c_int64_p, c_int_p, c_double_p]),
     ("gp_synchronize", ctypes.c_int, [_vp]),
     ("gp_set_option", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
 ]
@@ -256,6 +257,13 @@ class Handle(object):
         check(self.lib, self.lib.gp_gemm_stats(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)),
               "gp_gemm_stats")
         return dict(launches=n.value, ms=ms.value, flops=fl.value)
+
+    def gemm_trace(self, cap=100000):
+        tiles = np.empty(cap, dtype=np.int64)
+        K = np.empty(cap, dtype=np.int32)
+        ms = np.empty(cap)
+        n = self.lib.gp_gemm_trace(self.h, cap, tiles.ctypes.data_as(c_int64_p), K.ctypes.data_as(c_int_p), dptr(ms))
+        return tiles[:n], K[:n], ms[:n]
 
     def synchronize(self):
         check(self.lib, self.lib.gp_synchronize(self.h), "gp_synchronize")

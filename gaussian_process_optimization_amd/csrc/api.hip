@@ -3,6 +3,7 @@
 #include "gphip_internal.h"
 #include "../../include/gphip.h"
 
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -46,7 +47,10 @@ struct Phase {
 struct gp_ctx {
     int device = 0;
     hipStream_t s = nullptr;       // main stream
-    hipStream_t s_panel = nullptr; // look-ahead (panel) stream, high priority
+    hipStream_t s_panel = nullptr; // look-ahead (panel chain) stream: high priority, all CUs
+    hipStream_t s_bulk = nullptr;  // trailing-update stream of the look-ahead Cholesky: masked off the reserved CUs
+    int bulk_reserved = -1;        // reserved-CU count s_bulk was created with
+    std::vector<hipEvent_t> la_events;
     // data
     long N = 0, Npad = 0;
     int D = 0, P = 0;
@@ -84,19 +88,28 @@ struct gp_ctx {
     double *dWi = nullptr;
     long capWi = 0;
     bool wi_valid = false;
-    double *dT2 = nullptr;
+    double *dT2 = nullptr;   // solved candidate rows S = K(Xs,X) L^-T (the running right-hand side stays in dT)
     long capT2 = 0;
+    double *dCov = nullptr;  // full covariance / beta scratch
+    long capCov = 0;
+    double *dInvP = nullptr, *dInvPw = nullptr;  // inverted diagonal panels L_JJ^-1 (+ build workspace)
+    long capInvP = 0, capInvPw = 0;
+    int invp_W = 0;
+    bool invp_valid = false;
     double *dDm = nullptr, *dDv = nullptr, *dDacq = nullptr;
     long capD = 0;
     // options
-    int panel_tiles = 4;
-    int lookahead = 0;
+    int panel_tiles = 8;
+    int lookahead = 1;
+    int reserve_cus = 8;
     long mc_max = 16384;
     // profiling
     Phase phases[MAX_PHASES];
     int nphases = 0;
     bool profiling = false;
     std::vector<hipEvent_t> gemm_events;
+    std::vector<long> gemm_tiles;
+    std::vector<int> gemm_K;
     size_t gemm_ev_used = 0;
     long gemm_launches = 0;
     double gemm_flops = 0.0;
@@ -128,8 +141,8 @@ static void phase_end(gp_ctx *g, int id) {
 
 // ---- GEMM wrapper with accounting ---------------------------------------------------------------
 static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const double *A, long lda, const double *B,
-                 long ldb, int b_mul, int K, TileSet ts, int k_tri = 0) {
-    const long n = tileset_count(ts);
+                 long ldb, int b_mul, int K, TileSet ts, const GemmOpt &o = GemmOpt()) {
+    const long n = tileset_count(ts) * o.batch;
     if (n <= 0 || K <= 0) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g->profiling) {
@@ -143,11 +156,13 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
         e0 = g->gemm_events[g->gemm_ev_used++];
         e1 = g->gemm_events[g->gemm_ev_used++];
         hipEventRecord(e0, s);
+        g->gemm_tiles.push_back(n);
+        g->gemm_K.push_back((o.k_tri || o.k_end_tri) ? -K : K);
     }
-    launch_gemm_nt(s, mode, C, ldc, A, lda, B, ldb, b_mul, K, ts, k_tri);
+    launch_gemm_nt(s, mode, C, ldc, A, lda, B, ldb, b_mul, K, ts, o);
     if (g->profiling) hipEventRecord(e1, s);
     g->gemm_launches++;
-    g->gemm_flops += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n * (k_tri ? 0.5 : 1.0);
+    g->gemm_flops += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n * ((o.k_tri || o.k_end_tri) ? 0.5 : 1.0);
 }
 
 // ---- memory helpers -----------------------------------------------------------------------------
@@ -218,7 +233,7 @@ int gp_destroy(gp_t *g) {
     hipDeviceSynchronize();
     if (g->comm) ncclCommDestroy(g->comm);
     double *ptrs[] = {g->dX, g->dY, g->dA, g->dInvL, g->dAlpha, g->dW, g->dMu, g->dScal, g->dRedV,
-                      g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi, g->dT2, g->dDm, g->dDv, g->dDacq};
+                      g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi, g->dT2, g->dDm, g->dDv, g->dDacq, g->dCov, g->dInvP, g->dInvPw};
     for (double *p : ptrs)
         if (p) hipFree(p);
     if (g->dInfo) hipFree(g->dInfo);
@@ -231,6 +246,8 @@ int gp_destroy(gp_t *g) {
     for (hipEvent_t e : g->gemm_events) hipEventDestroy(e);
     if (g->s) hipStreamDestroy(g->s);
     if (g->s_panel) hipStreamDestroy(g->s_panel);
+    if (g->s_bulk) hipStreamDestroy(g->s_bulk);
+    for (hipEvent_t e : g->la_events) hipEventDestroy(e);
     delete g;
     return 0;
 }
@@ -242,6 +259,9 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->panel_tiles = (int)value;
     } else if (!strcmp(name, "lookahead")) {
         g->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "reserve_cus")) {
+        if (value < 0 || value > 64) return fail(GP_ERR_ARG, "reserve_cus out of range");
+        g->reserve_cus = (int)value;
     } else if (!strcmp(name, "mc_max")) {
         if (value < GP_TILE) return fail(GP_ERR_ARG, "mc_max < 128");
         g->mc_max = round_up(value, GP_TILE);
@@ -254,6 +274,7 @@ int gp_synchronize(gp_t *g) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(hipStreamSynchronize(g->s_panel));
+    if (g->s_bulk) HIPCHK(hipStreamSynchronize(g->s_bulk));
     HIPCHK(hipStreamSynchronize(g->s));
     return 0;
 }
@@ -294,6 +315,7 @@ int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N, int D, int
     g->fitted = false;
     g->fmin_valid = false;
     g->wi_valid = false;
+    g->invp_valid = false;
     g->predicted = false;
     g->kp.D = D;
     return 0;
@@ -313,6 +335,7 @@ int gp_set_params(gp_t *g, int kernel, int ard, double variance, const double *l
     g->fitted = false;
     g->fmin_valid = false;
     g->wi_valid = false;
+    g->invp_valid = false;
     g->predicted = false;
     return 0;
 }
@@ -344,6 +367,172 @@ static void factor(gp_ctx *g) {
     }
 }
 
+// ---- the same factorisation with one panel of look-ahead on three streams ----------------------------
+// s_panel (high priority, every CU): the latency chain of panel J -- potrf tile, panel solve, in-panel
+//          updates -- then the update of panel J+1's columns with panel J (so that chain J+1 can start);
+// s_bulk  (masked off `reserve_cus` CUs, which therefore stay free for the chain's single-workgroup potrf
+//          kernel whose 148 KB of LDS needs an otherwise empty CU): the update of every column right of
+//          panel J+1 with panel J -- the dense contraction, >90 % of the flops;
+// s       : everything before and after.
+// Ordering: bulk(J) after chain(J); look-ahead update(J) after bulk(J-1) (both touch panel J+1's columns);
+// bulk(J) after bulk(J-1) (stream order).  Column sets of concurrent kernels are disjoint by construction.
+static int ensure_bulk_stream(gp_ctx *g) {
+    if (g->s_bulk && g->bulk_reserved == g->reserve_cus) return 0;
+    if (g->s_bulk) {
+        hipStreamSynchronize(g->s_bulk);
+        hipStreamDestroy(g->s_bulk);
+        g->s_bulk = nullptr;
+    }
+    hipDeviceProp_t pr;
+    HIPCHK(hipGetDeviceProperties(&pr, g->device));
+    const int ncu = pr.multiProcessorCount;
+    const int words = (ncu + 31) / 32;
+    std::vector<uint32_t> mask(words, 0xffffffffu);
+    // CU bits are dealt round-robin over the XCDs (measured: tools/micro/cumask.hip), so clearing the
+    // lowest R bits reserves R/8 CUs on every XCD.
+    for (int i = 0; i < g->reserve_cus && i < ncu - 8; ++i) mask[i / 32] &= ~(1u << (i % 32));
+    if (g->reserve_cus > 0) {
+        hipError_t e = hipExtStreamCreateWithCUMask(&g->s_bulk, (uint32_t)words, mask.data());
+        if (e != hipSuccess) return fail(GP_ERR_HIP, "hipExtStreamCreateWithCUMask -> %s", hipGetErrorString(e));
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&g->s_bulk, hipStreamNonBlocking));
+    }
+    g->bulk_reserved = g->reserve_cus;
+    return 0;
+}
+
+static hipEvent_t la_event(gp_ctx *g, size_t i) {
+    while (g->la_events.size() <= i) {
+        hipEvent_t e;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        g->la_events.push_back(e);
+    }
+    return g->la_events[i];
+}
+
+static int factor_lookahead(gp_ctx *g) {
+    int rc;
+    if ((rc = ensure_bulk_stream(g))) return rc;
+    const long lda = g->Npad;
+    const int nt = (int)(g->Npad / GP_TILE);
+    const int R1 = nt + 1;
+    const int W = g->panel_tiles;
+    const int nJ = (nt + W - 1) / W;
+    double *A = g->dA;
+    hipStream_t sp = g->s_panel, sb = g->s_bulk;
+    // fork
+    hipEvent_t e0 = la_event(g, 0);
+    hipEventRecord(e0, g->s);
+    hipStreamWaitEvent(sp, e0, 0);
+    hipStreamWaitEvent(sb, e0, 0);
+    // events: 1 + 2J = chain(J) done, 2 + 2J = bulk(J) done
+    for (int J = 0; J < nJ; ++J) {
+        const int J0 = J * W, J1 = std::min(J0 + W, nt), J2 = std::min(J1 + W, nt);
+        for (int j = J0; j < J1; ++j) {
+            launch_potrf_tile(sp, A, lda, j, g->dInvL, g->dInfo);
+            gemm(g, sp, 0, A, lda, A + (long)j * GP_TILE, lda, g->dInvL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0,
+                 GP_TILE, TileSet{j + 1, R1, j, j + 1, 0});
+            if (j + 1 < J1)
+                gemm(g, sp, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE,
+                     TileSet{0, R1, j + 1, J1, 1});
+        }
+        if (J1 >= nt) break;
+        hipEvent_t eF = la_event(g, 1 + 2 * J);
+        hipEventRecord(eF, sp);
+        const int K = (J1 - J0) * GP_TILE;
+        if (J2 < nt) {
+            hipStreamWaitEvent(sb, eF, 0);
+            gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
+                 TileSet{0, R1, J2, nt, 1});
+            hipEventRecord(la_event(g, 2 + 2 * J), sb);
+        }
+        if (J >= 1) hipStreamWaitEvent(sp, la_event(g, 2 + 2 * (J - 1)), 0);
+        gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
+             TileSet{0, R1, J1, J2, 1});
+    }
+    // join
+    hipEvent_t ep = la_event(g, 1 + 2 * nJ + 1), eb = la_event(g, 1 + 2 * nJ + 2);
+    hipEventRecord(ep, sp);
+    hipEventRecord(eb, sb);
+    hipStreamWaitEvent(g->s, ep, 0);
+    hipStreamWaitEvent(g->s, eb, 0);
+    return 0;
+}
+
+// ---- inverted diagonal panels ---------------------------------------------------------------------
+// invP_J = L_JJ^-1 for every panel J of W tiles (PB = W*128 rows), so that every triangular solve
+// against L -- candidates (dtrtrs, posterior.py:294), alpha (dpotrs, exact_gaussian_inference.py:60),
+// Ky^-1 (dpotri, linalg.py:127-145) -- is ONE product per panel on the MFMA GEMM instead of a chain of
+// W dependent 128-column steps.  Built batched over all panels at once: the solve of the identity
+// against L_JJ (2W-1 small launches, each covering every panel) gives L_JJ^-T, then one transpose.
+static int ensure_panel_inv(gp_ctx *g) {
+    if (g->invp_valid && g->invp_W == g->panel_tiles) return 0;
+    const long Npad = g->Npad, lda = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    const int W = std::min(g->panel_tiles, nt);
+    const long PB = (long)W * GP_TILE;
+    const int nJ = (nt + W - 1) / W, nF = nt / W, Wl = nt % W;
+    int rc;
+    if ((rc = dev_realloc(&g->dInvP, &g->capInvP, (long)nJ * PB * PB))) return rc;
+    if ((rc = dev_realloc(&g->dInvPw, &g->capInvPw, (long)nJ * PB * PB))) return rc;
+    double *Wk = g->dInvPw;
+    hipStream_t s = g->s;
+    launch_set_identity_blocks(s, Wk, PB, nJ);
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0: the nF full panels as one batch; pass 1: the ragged last panel (Wl tiles)
+        const int batch = pass == 0 ? nF : (Wl ? 1 : 0), Wp = pass == 0 ? W : Wl;
+        if (batch == 0) continue;
+        const long z0 = pass == 0 ? 0 : nF;
+        double *Wb = Wk + z0 * PB * PB;
+        const double *Lb = g->dA + z0 * (PB * lda + PB);
+        const double *Ib = g->dInvL + z0 * (long)W * GP_TILE * GP_TILE;
+        for (int b = 0; b < Wp; ++b) {
+            GemmOpt o;
+            o.batch = batch;
+            o.sC = o.sA = PB * PB;
+            o.sB = (long)W * GP_TILE * GP_TILE;
+            gemm(g, s, 0, Wb, PB, Wb + (long)b * GP_TILE, PB, Ib + (long)b * GP_TILE * GP_TILE, GP_TILE, 0, GP_TILE,
+                 TileSet{0, b + 1, b, b + 1, 0}, o);
+            if (b + 1 < Wp) {
+                o.sB = PB * lda + PB;
+                gemm(g, s, 1, Wb, PB, Wb + (long)b * GP_TILE, PB, Lb + (long)b * GP_TILE, lda, 1, GP_TILE,
+                     TileSet{0, b + 1, b + 1, Wp, 0}, o);
+            }
+        }
+    }
+    launch_transpose_blocks(s, g->dInvP, Wk, PB, nJ);
+    g->invp_W = W;
+    g->invp_valid = true;
+    return 0;
+}
+
+// Row solve  S = T L^-T  for `mt` row tiles of T (row-major, ld = Npad); T is consumed as the running
+// right-hand side.  trapezoid = 1: T is block upper-triangular (row tile r is zero left of column tile r:
+// the identity, for L^-T), so panel J only touches the row tiles above its end.
+static void solve_rows(gp_ctx *g, double *T, double *S, int mt, int trapezoid) {
+    const long Npad = g->Npad, lda = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    const int W = g->invp_W;
+    const long PB = (long)W * GP_TILE;
+    const double *L = g->dA;
+    hipStream_t s = g->s;
+    for (int J0 = 0, J = 0; J0 < nt; J0 += W, ++J) {
+        const int J1 = std::min(J0 + W, nt);
+        const int Kp = (J1 - J0) * GP_TILE;
+        const int rows = trapezoid ? std::min(mt, J1) : mt;
+        GemmOpt o;
+        o.k_end_tri = 1;
+        o.b_sub = J0;
+        // S[:, J] = T[:, J] invP_J^T   (invP_J lower triangular: column tile c contracts k <= c)
+        gemm(g, s, 0, S, Npad, T + (long)J0 * GP_TILE, Npad, g->dInvP + (long)J * PB * PB, PB, 1, Kp,
+             TileSet{0, rows, J0, J1, 0}, o);
+        // T[:, > J] -= S[:, J] L[> J, J]^T
+        if (J1 < nt)
+            gemm(g, s, 1, T, Npad, S + (long)J0 * GP_TILE, Npad, L + (long)J0 * GP_TILE, lda, 1, Kp,
+                 TileSet{0, rows, J1, nt, 0});
+    }
+}
+
 __global__ void dot_ay_kernel(const double *alpha, long lda_, const double *Y, long N, int P, double *out) {
     __shared__ double sh[16];
     const int p = blockIdx.x;
@@ -372,6 +561,7 @@ int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_us
     g->fitted = false;
     g->fmin_valid = false;
     g->wi_valid = false;
+    g->invp_valid = false;
     g->predicted = false;
 
     double jitter = 0.0;
@@ -386,7 +576,12 @@ int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_us
         phase_end(g, ph);
         HIPCHK(hipMemsetAsync(g->dInfo, 0, sizeof(int) * 4, g->s));
         ph = phase_begin(g, "cholesky", (double)N * N * N / 3.0, 0.0);
-        factor(g);
+        if (g->lookahead && Npad / GP_TILE > g->panel_tiles) {
+            int rcf = factor_lookahead(g);
+            if (rcf) return rcf;
+        } else {
+            factor(g);
+        }
         phase_end(g, ph);
         HIPCHK(hipMemcpyAsync(&info, g->dInfo, sizeof(int), hipMemcpyDeviceToHost, g->s));
         HIPCHK(hipStreamSynchronize(g->s));
@@ -408,7 +603,11 @@ int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_us
 
     int ph = phase_begin(g, "alpha_lml", 2.0 * (double)N * N * P, 8.0 * (double)N * N / 2);
     launch_logdet(g->s, g->dA, lda, N, g->dScal);
-    launch_trsv_backward(g->s, g->dA, lda, g->dInvL, Npad, g->dA + Npad * lda, lda, P, g->dAlpha, g->dW);
+    {
+        int rci = ensure_panel_inv(g);
+        if (rci) return rci;
+    }
+    launch_trsv_backward(g->s, g->dA, lda, g->dInvP, g->invp_W, Npad, g->dA + Npad * lda, lda, P, g->dAlpha, g->dW);
     hipLaunchKernelGGL(dot_ay_kernel, dim3(P), dim3(1024), 0, g->s, g->dAlpha, Npad, g->dY, N, P, g->dScal + 8);
     phase_end(g, ph);
     std::vector<double> sc(8 + P);
@@ -460,6 +659,7 @@ int gp_kernel_matrix(gp_t *g, double *K) {
                        hipMemcpyDeviceToHost));
     g->fitted = false;  // dA was overwritten
     g->wi_valid = false;
+    g->invp_valid = false;
     g->predicted = false;
     return 0;
 }
@@ -479,30 +679,6 @@ int gp_set_candidates(gp_t *g, const double *Xs, int64_t M) {
     return 0;
 }
 
-// candidate solve on the resident chunk: T <- T L^-T  (T = K(Xs, X), candidate-major)
-static void solve_candidates(gp_ctx *g, long mcpad) {
-    const long Npad = g->Npad, lda = g->Npad;
-    const int nt = (int)(Npad / GP_TILE);
-    const int mt = (int)(mcpad / GP_TILE);
-    const int W = g->panel_tiles;
-    double *T = g->dT;
-    const double *L = g->dA;
-    hipStream_t s = g->s;
-    for (int J0 = 0; J0 < nt; J0 += W) {
-        const int J1 = std::min(J0 + W, nt);
-        for (int b = J0; b < J1; ++b) {
-            gemm(g, s, 0, T, Npad, T + (long)b * GP_TILE, Npad, g->dInvL + (long)b * GP_TILE * GP_TILE, GP_TILE, 0,
-                 GP_TILE, TileSet{0, mt, b, b + 1, 0});
-            if (b + 1 < J1)
-                gemm(g, s, 1, T, Npad, T + (long)b * GP_TILE, Npad, L + (long)b * GP_TILE, lda, 1, GP_TILE,
-                     TileSet{0, mt, b + 1, J1, 0});
-        }
-        if (J1 < nt)
-            gemm(g, s, 1, T, Npad, T + (long)J0 * GP_TILE, Npad, L + (long)J0 * GP_TILE, lda, 1, (J1 - J0) * GP_TILE,
-                 TileSet{0, mt, J1, nt, 0});
-    }
-}
-
 static int run_predict(gp_ctx *g, int include_noise) {
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
@@ -512,7 +688,9 @@ static int run_predict(gp_ctx *g, int include_noise) {
     int rc;
     g->nphases = 0;
     const long mc_max = std::min(g->mc_max, round_up(M, GP_TILE));
+    if ((rc = ensure_panel_inv(g))) return rc;
     if ((rc = dev_realloc(&g->dT, &g->capT, mc_max * Npad))) return rc;
+    if ((rc = dev_realloc(&g->dT2, &g->capT2, mc_max * Npad))) return rc;
     for (long m0 = 0; m0 < M; m0 += mc_max) {
         const long mc = std::min(mc_max, M - m0);
         const long mcpad = round_up(mc, GP_TILE);
@@ -520,10 +698,10 @@ static int run_predict(gp_ctx *g, int include_noise) {
         launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, g->N, Npad, g->kp);
         phase_end(g, ph);
         ph = phase_begin(g, "cand_solve", (double)N * N * mc, 0.0);
-        solve_candidates(g, mcpad);
+        solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), 0);
         phase_end(g, ph);
         ph = phase_begin(g, "reduce", 0.0, 8.0 * (double)N * mc);
-        launch_predict_reduce(g->s, g->dT, Npad, mc, N, g->dA + Npad * Npad, Npad, P, g->kp.variance,
+        launch_predict_reduce(g->s, g->dT2, Npad, mc, N, g->dA + Npad * Npad, Npad, P, g->kp.variance,
                               include_noise ? g->noise : 0.0, g->dMean + m0 * P, g->dVar + m0);
         phase_end(g, ph);
     }
@@ -642,6 +820,8 @@ int gp_profile(gp_t *g, int on) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
     g->profiling = on != 0;
     g->gemm_ev_used = 0;
+    g->gemm_tiles.clear();
+    g->gemm_K.clear();
     g->gemm_launches = 0;
     g->gemm_flops = 0.0;
     return 0;
@@ -651,6 +831,7 @@ int gp_gemm_stats(gp_t *g, int64_t *launches, double *ms, double *flops) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
     hipSetDevice(g->device);
     hipStreamSynchronize(g->s_panel);
+    if (g->s_bulk) hipStreamSynchronize(g->s_bulk);
     hipStreamSynchronize(g->s);
     double tot = 0.0;
     for (size_t i = 0; i + 1 < g->gemm_ev_used; i += 2) {
@@ -661,6 +842,23 @@ int gp_gemm_stats(gp_t *g, int64_t *launches, double *ms, double *flops) {
     if (ms) *ms = tot;
     if (flops) *flops = g->gemm_flops;
     return 0;
+}
+
+int gp_gemm_trace(gp_t *g, int cap, int64_t *tiles, int *K, double *ms) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    hipSetDevice(g->device);
+    hipStreamSynchronize(g->s_panel);
+    if (g->s_bulk) hipStreamSynchronize(g->s_bulk);
+    hipStreamSynchronize(g->s);
+    int n = (int)std::min<size_t>((size_t)cap, g->gemm_tiles.size());
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        hipEventElapsedTime(&t, g->gemm_events[2 * i], g->gemm_events[2 * i + 1]);
+        if (tiles) tiles[i] = g->gemm_tiles[i];
+        if (K) K[i] = g->gemm_K[i];
+        if (ms) ms[i] = t;
+    }
+    return n;
 }
 
 // ---- multi-GPU --------------------------------------------------------------------------------------
@@ -740,6 +938,7 @@ int gp_comm_bcast_fit(gp_t *g, int root) {
     g->fitted = true;
     g->fmin_valid = false;
     g->wi_valid = false;
+    g->invp_valid = false;
     g->predicted = false;
     return 0;
 }
@@ -755,29 +954,21 @@ static int ensure_wi(gp_ctx *g) {
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     const long Npad = g->Npad, lda = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
-    const int Wt = g->panel_tiles;
     int rc;
+    if ((rc = ensure_panel_inv(g))) return rc;
     if ((rc = dev_realloc(&g->dT, &g->capT, Npad * Npad))) return rc;
+    if ((rc = dev_realloc(&g->dT2, &g->capT2, Npad * Npad))) return rc;
     if ((rc = dev_realloc(&g->dWi, &g->capWi, Npad * Npad))) return rc;
     double *T = g->dT;
-    const double *L = g->dA;
     hipStream_t s = g->s;
     int ph = phase_begin(g, "potri", 2.0 * (double)g->N * g->N * g->N / 3.0, 0.0);
     launch_set_identity(s, T, Npad, Npad);
-    for (int J0 = 0; J0 < nt; J0 += Wt) {
-        const int J1 = std::min(J0 + Wt, nt);
-        for (int b = J0; b < J1; ++b) {
-            gemm(g, s, 0, T, Npad, T + (long)b * GP_TILE, Npad, g->dInvL + (long)b * GP_TILE * GP_TILE, GP_TILE, 0,
-                 GP_TILE, TileSet{0, b + 1, b, b + 1, 0});
-            if (b + 1 < J1)
-                gemm(g, s, 1, T, Npad, T + (long)b * GP_TILE, Npad, L + (long)b * GP_TILE, lda, 1, GP_TILE,
-                     TileSet{0, b + 1, b + 1, J1, 0});
-        }
-        if (J1 < nt)
-            gemm(g, s, 1, T, Npad, T + (long)J0 * GP_TILE, Npad, L + (long)J0 * GP_TILE, lda, 1, (J1 - J0) * GP_TILE,
-                 TileSet{0, J1, J1, nt, 0});
+    solve_rows(g, T, g->dT2, nt, 1);  // dT2 = L^-T (block upper triangular)
+    {
+        GemmOpt o;
+        o.k_tri = 1;
+        gemm(g, s, 0, g->dWi, Npad, g->dT2, Npad, g->dT2, Npad, 1, (int)Npad, TileSet{0, nt, 0, nt, 1}, o);
     }
-    gemm(g, s, 0, g->dWi, Npad, T, Npad, T, Npad, 1, (int)Npad, TileSet{0, nt, 0, nt, 1}, 1);
     launch_symmetrize(s, g->dWi, Npad, Npad);
     phase_end(g, ph);
     g->wi_valid = true;
@@ -835,9 +1026,9 @@ int gp_lml_grad(gp_t *g, double *dvariance, double *dlengthscale, double *dnoise
 }
 
 // ---- second candidate-sized buffer (beta = K(Xs,X) Ky^-1, or the full covariance) -----------------
-static int ensure_grad_buffers(gp_ctx *g, long elemsT2, long M) {
+static int ensure_grad_buffers(gp_ctx *g, long elemsBeta, long M) {
     int rc;
-    if ((rc = dev_realloc(&g->dT2, &g->capT2, elemsT2))) return rc;
+    if ((rc = dev_realloc(&g->dCov, &g->capCov, elemsBeta))) return rc;
     const long need = M * (long)g->D * std::max(1, g->P);
     if (!g->dDm || g->capD < need) {
         for (double **b : {&g->dDm, &g->dDv, &g->dDacq}) {
@@ -869,8 +1060,8 @@ static int run_predict_grad(gp_ctx *g) {
         const int mt = (int)(mcpad / GP_TILE);
         launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, N, Npad, g->kp);
         // beta = K(Xs, X) Ky^-1   (gp.py:451-452; Ky^-1 symmetric => rows of Wi serve as the B operand)
-        gemm(g, g->s, 0, g->dT2, Npad, g->dT, Npad, g->dWi, Npad, 1, (int)Npad, TileSet{0, mt, 0, nt, 0});
-        launch_predict_grad(g->s, g->dXs + m0 * g->D, mc, g->dX, N, g->kp, g->dAlpha, Npad, g->P, g->dT2, Npad,
+        gemm(g, g->s, 0, g->dCov, Npad, g->dT, Npad, g->dWi, Npad, 1, (int)Npad, TileSet{0, mt, 0, nt, 0});
+        launch_predict_grad(g->s, g->dXs + m0 * g->D, mc, g->dX, N, g->kp, g->dAlpha, Npad, g->P, g->dCov, Npad,
                             g->dDm + m0 * g->D * g->P, g->dDv + m0 * g->D);
     }
     g->predicted = false;  // dT no longer holds the solved candidates
@@ -917,15 +1108,15 @@ int gp_predict_full_cov(gp_t *g, int include_noise, double *mean, double *cov) {
     if (Mpad > g->mc_max) return fail(GP_ERR_ARG, "full covariance needs M <= mc_max (%ld)", g->mc_max);
     int rc;
     if ((rc = ensure_out(g))) return rc;
-    if ((rc = run_predict(g, include_noise))) return rc;  // leaves T = K(Xs,X) L^-T in dT (single chunk)
-    if ((rc = dev_realloc(&g->dT2, &g->capT2, std::max(g->capT2, Mpad * Mpad)))) return rc;
+    if ((rc = run_predict(g, include_noise))) return rc;  // leaves S = K(Xs,X) L^-T in dT2 (single chunk)
+    if ((rc = dev_realloc(&g->dCov, &g->capCov, std::max(g->capCov, Mpad * Mpad)))) return rc;
     const int mt = (int)(Mpad / GP_TILE);
-    launch_kbuild(g->s, g->dT2, Mpad, g->dXs, M, Mpad, g->kp, 0.0, 1);  // K(Xs, Xs)
-    gemm(g, g->s, 1, g->dT2, Mpad, g->dT, Npad, g->dT, Npad, 1, (int)Npad, TileSet{0, mt, 0, mt, 0});
-    if (include_noise) launch_add_diag(g->s, g->dT2, Mpad, M, g->noise);  // gaussian.py:104-105
+    launch_kbuild(g->s, g->dCov, Mpad, g->dXs, M, Mpad, g->kp, 0.0, 1);  // K(Xs, Xs)
+    gemm(g, g->s, 1, g->dCov, Mpad, g->dT2, Npad, g->dT2, Npad, 1, (int)Npad, TileSet{0, mt, 0, mt, 0});
+    if (include_noise) launch_add_diag(g->s, g->dCov, Mpad, M, g->noise);  // gaussian.py:104-105
     if (mean) HIPCHK(hipMemcpyAsync(mean, g->dMean, sizeof(double) * M * g->P, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipStreamSynchronize(g->s));
-    HIPCHK(hipMemcpy2D(cov, sizeof(double) * M, g->dT2, sizeof(double) * Mpad, sizeof(double) * M, M,
+    HIPCHK(hipMemcpy2D(cov, sizeof(double) * M, g->dCov, sizeof(double) * Mpad, sizeof(double) * M, M,
                        hipMemcpyDeviceToHost));
     return 0;
 }

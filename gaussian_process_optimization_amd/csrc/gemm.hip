@@ -23,9 +23,25 @@
 //
 // Roofline: algorithmic flops per launch = 2 * 128*128 * K * ntiles; bound = fp64 MFMA.
 #include "gphip_internal.h"
+#include <algorithm>
 
 #define BK 16
 #define LSTR 18  // LDS row pitch in doubles
+
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+// C tile traffic goes through buffer instructions: one SGPR descriptor per wave, the lane part of the
+// address as a single 32-bit VGPR offset and the row stride as an SGPR offset, instead of 16 64-bit
+// VGPR row pointers that would otherwise live across the whole K loop.
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v[1], (int)v[0]);
+}
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double d) {
+    v2u_t v;
+    v[0] = (unsigned)__double2loint(d);
+    v[1] = (unsigned)__double2hiint(d);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
 
 struct GemmArgs {
     double *C;
@@ -37,7 +53,11 @@ struct GemmArgs {
     int b_mul;
     int K;
     int r0, r1, c0, c1, tri;
-    int k_tri;  // contraction starts at column ti*128 (A is block upper-triangular: lauum-type products)
+    int k_tri;      // contraction starts at column ti*128 (A is block upper-triangular: lauum-type products)
+    int k_end_tri;  // contraction ends after column tile (tc - b_sub): B is block lower-triangular
+    int b_sub;      // B row tile = (tc - b_sub) * b_mul
+    long sC, sA, sB;  // batch strides (elements) applied with blockIdx.y
+    const short *tile_list;  // optional explicit (row tile, col tile) order (L2-friendly super-tiles)
 };
 
 __device__ __forceinline__ void tile_from_linear(long t, const GemmArgs &a, int &i, int &c) {
@@ -76,16 +96,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     const long wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
 
     int ti, tc;
-    tile_from_linear(wg, a, ti, tc);
+    if (a.tile_list) {
+        ti = a.tile_list[2 * wg];
+        tc = a.tile_list[2 * wg + 1];
+    } else {
+        tile_from_linear(wg, a, ti, tc);
+    }
+    // the triangular decode goes through a VALU sqrt: tell the compiler the result is wave-uniform
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    tc = __builtin_amdgcn_readfirstlane(tc);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: C addressing stays scalar
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
 
+    const long z = blockIdx.y;
     const int kstart = a.k_tri ? ti * GP_TILE : 0;
-    const double *Ag = a.A + (long)ti * GP_TILE * a.lda + kstart;
-    const double *Bg = a.B + (long)tc * a.b_mul * GP_TILE * a.ldb + kstart;
+    const int kend = a.k_end_tri ? (tc - a.b_sub + 1) * GP_TILE : a.K;
+    const double *Ag = a.A + z * a.sA + (long)ti * GP_TILE * a.lda + kstart;
+    const double *Bg = a.B + z * a.sB + (long)(tc - a.b_sub) * a.b_mul * GP_TILE * a.ldb + kstart;
 
     // staging map: 128 rows x 8 chunks(16 B); thread handles rows (tid>>3) + 32q, chunk tid&7
     const int srow = tid >> 3, sch = (tid & 7) * 2;
@@ -94,14 +125,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     const long a32 = 32 * a.lda, b32 = 32 * a.ldb;
     const int soff = srow * LSTR + sch;
 
+    // accumulator element r of tile (m,n) is C[row = lg + 4r][col = li] of that 16x16 tile
+    double *Cw = a.C + z * a.sC + ((long)ti * GP_TILE + wm * 64) * a.ldc + (long)tc * GP_TILE + wn * 64;  // uniform
+    const unsigned cbyte = (unsigned)(lg * (int)a.ldc + li) * 8u;  // lane part of the address, bytes
+    const unsigned crow = (unsigned)a.ldc * 8u;                    // row stride, bytes (wave tile spans 64 rows: < 2^31)
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(Cw, 0, 0x7fffffff, 0x00020000);
     double4_t acc[4][4];
+    if (MODE == 1) {
+        // C -= A B^T: the old C rides in as the MFMA C operand (A negated by the f64 MFMA neg modifier), so
+        // its HBM read overlaps the first operand-tile loads and the epilogue is stores only.
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[m][n][r] = buf_load_f64(crs, cbyte + n * 128, (unsigned)(m * 16 + 4 * r) * crow);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
 
     double2_t ra[4], rb[4];
-    const int nk = (a.K - kstart) / BK;
+    const int nk = (kend - kstart) / BK;
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -150,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m][e], bf[n][e], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m][e], bf[n][e], acc[m][n], 0, 0, MODE == 1 ? 1 : 0);
         }
         if (more) {
             double *As = smem + (buf ^ 1) * (2 * GP_TILE * LSTR), *Bs = As + GP_TILE * LSTR;
@@ -163,35 +211,44 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
         __syncthreads();
     }
 
-    // epilogue: accumulator element r of tile (m,n) is C[row = lg + 4r][col = li] of that 16x16 tile
-    double *Cg = a.C + ((long)ti * GP_TILE + wm * 64 + lg) * a.ldc + (long)tc * GP_TILE + wn * 64 + li;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double *p = Cg + (long)(m * 16 + 4 * r) * a.ldc + n * 16;
-                if (MODE == 0)
-                    *p = acc[m][n][r];
-                else
-                    *p = *p - acc[m][n][r];
-            }
-        }
-    }
+            for (int r = 0; r < 4; ++r)
+                buf_store_f64(crs, cbyte + n * 128, (unsigned)(m * 16 + 4 * r) * crow, acc[m][n][r]);
 }
 
 void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *A, long lda,
-                    const double *B, long ldb, int b_mul, int K, TileSet ts, int k_tri) {
+                    const double *B, long ldb, int b_mul, int K, TileSet ts, const GemmOpt &o) {
     long n = tileset_count(ts);
-    if (n <= 0 || K <= 0) return;
+    if (n <= 0 || K <= 0 || o.batch <= 0) return;
     GemmArgs a;
     a.C = C; a.ldc = ldc; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
     a.b_mul = b_mul; a.K = K;
     a.r0 = ts.r0; a.r1 = ts.r1; a.c0 = ts.c0; a.c1 = ts.c1; a.tri = ts.tri;
-    a.k_tri = k_tri;
+    a.k_tri = o.k_tri; a.k_end_tri = o.k_end_tri; a.b_sub = o.b_sub;
+    a.sC = o.sC; a.sA = o.sA; a.sB = o.sB;
+    a.tile_list = o.tile_list;
+    dim3 grid((unsigned)n, (unsigned)o.batch);
     if (mode == 0)
-        hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)n), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)n), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, s, a);
+}
+
+std::vector<short> build_tile_list(const TileSet &ts, int S) {
+    std::vector<short> out;
+    const int c_lo = ts.c0, c_hi = ts.c1;
+    const int r_lo = ts.tri ? ts.c0 : ts.r0, r_hi = ts.r1;
+    for (int sc = c_lo; sc < c_hi; sc += S)
+        for (int sr = (ts.tri ? sc : r_lo); sr < r_hi; sr += S)
+            for (int c = sc; c < std::min(sc + S, c_hi); ++c)
+                for (int i = sr; i < std::min(sr + S, r_hi); ++i) {
+                    if (ts.tri && i < c) continue;
+                    out.push_back((short)i);
+                    out.push_back((short)c);
+                }
+    return out;
 }

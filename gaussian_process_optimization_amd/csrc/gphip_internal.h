@@ -36,8 +36,19 @@ static inline long tileset_count(const TileSet &t) {
 // A rows   at A + i*128*lda            (K columns)
 // B rows   at B + (c*b_mul)*128*ldb    (K columns)
 // mode 0: C = A B^T ; mode 1: C -= A B^T
+struct GemmOpt {
+    int k_tri = 0;      // k starts at the output row tile (A block upper-triangular)
+    int k_end_tri = 0;  // k ends after column tile (tc - b_sub) (B block lower-triangular)
+    int b_sub = 0;      // B row tile = (tc - b_sub) * b_mul
+    int batch = 1;      // blockIdx.y instances with pointer strides sC, sA, sB (elements)
+    long sC = 0, sA = 0, sB = 0;
+    const short *tile_list = nullptr;  // device pointer, 2 shorts per tile, tileset_count(ts) tiles
+};
+// Host-side construction of an L2-friendly order: the tile set is cut into S x S super-tiles; the
+// list is dealt so that each XCD's contiguous run (see the remap in gemm.hip) walks whole super-tiles.
+std::vector<short> build_tile_list(const TileSet &ts, int S);
 void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *A, long lda,
-                    const double *B, long ldb, int b_mul, int K, TileSet ts, int k_tri = 0);
+                    const double *B, long ldb, int b_mul, int K, TileSet ts, const GemmOpt &o = GemmOpt());
 
 // Factor the 128x128 diagonal tile t of A (row-major, lda) in place (lower) and write
 // its inverse (row-major 128x128, lower, zero above) to invL + t*128*128.
@@ -59,8 +70,8 @@ void launch_logdet(hipStream_t s, const double *A, long lda, long N, double *out
 void launch_rhs_sumsq(hipStream_t s, const double *A, long lda, long N, long Npad, int P, double *out);
 
 // Backward substitution alpha = L^-T z using the inverse diagonal tiles.
-//   z rows: Z + p*ldz (p < P), alpha rows: Aout + p*ldz; w: workspace P*Npad.
-void launch_trsv_backward(hipStream_t s, const double *L, long lda, const double *invL, long Npad,
+//   z rows: Z + p*ldz (p < P), alpha rows: Aout + p*ldz; w: workspace P*Npad; invP: inverted diagonal panels.
+void launch_trsv_backward(hipStream_t s, const double *L, long lda, const double *invP, int W, long Npad,
                           const double *Z, long ldz, int P, double *Aout, double *w);
 
 // Row reductions over the solved candidate rows T[c, 0:N]:
@@ -95,3 +106,7 @@ void launch_acq_grad(hipStream_t s, int type, double par, double fmin, double y_
                      double *dout);
 void launch_add_diag(hipStream_t s, double *A, long lda, long N, double v);
 void launch_trace(hipStream_t s, const double *A, long lda, long N, double *out);
+
+// nb blocks of n x n (row-major, leading dimension n, stacked): identity / transpose (dst_b = src_b^T)
+void launch_set_identity_blocks(hipStream_t s, double *T, long n, int nb);
+void launch_transpose_blocks(hipStream_t s, double *dst, const double *src, long n, int nb);

@@ -331,3 +331,32 @@ __global__ __launch_bounds__(1024) void trace_kernel(const double *A, long lda, 
 void launch_trace(hipStream_t s, const double *A, long lda, long N, double *out) {
     hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1024), 0, s, A, lda, N, out);
 }
+
+__global__ void set_identity_blocks_kernel(double *T, long n) {
+    const long j2 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const long row = blockIdx.y;  // stacked row index over all blocks
+    if (j2 >= n) return;
+    const long i = row % n;
+    double2_t v;
+    v[0] = (i == j2) ? 1.0 : 0.0;
+    v[1] = (i == j2 + 1) ? 1.0 : 0.0;
+    *(double2_t *)(T + row * n + j2) = v;
+}
+void launch_set_identity_blocks(hipStream_t s, double *T, long n, int nb) {
+    dim3 grid((unsigned)((n / 2 + 255) / 256), (unsigned)(n * nb));
+    hipLaunchKernelGGL(set_identity_blocks_kernel, grid, dim3(256), 0, s, T, n);
+}
+__global__ void transpose_blocks_kernel(double *dst, const double *src, long n) {
+    __shared__ double t[32][33];
+    const long b = blockIdx.z;
+    const double *S = src + b * n * n;
+    double *D = dst + b * n * n;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) t[r][tx] = S[((long)blockIdx.y * 32 + r) * n + (long)blockIdx.x * 32 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) D[((long)blockIdx.x * 32 + r) * n + (long)blockIdx.y * 32 + tx] = t[tx][r];
+}
+void launch_transpose_blocks(hipStream_t s, double *dst, const double *src, long n, int nb) {
+    dim3 grid((unsigned)(n / 32), (unsigned)(n / 32), (unsigned)nb);
+    hipLaunchKernelGGL(transpose_blocks_kernel, grid, dim3(256), 0, s, dst, src, n);
+}

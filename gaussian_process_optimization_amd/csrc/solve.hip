@@ -3,6 +3,7 @@
 // All reductions are fixed-order (no float atomics) so results are bitwise reproducible.
 #include "gphip_internal.h"
 #include "../../include/gphip.h"
+#include <algorithm>
 
 // ---- block reduction helpers (256 or 1024 threads) ---------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -54,38 +55,78 @@ void launch_rhs_sumsq(hipStream_t s, const double *A, long lda, long N, long Npa
 }
 
 // ---- alpha = L^-T z  (second half of dpotrs, exact_gaussian_inference.py:60) -------------------
-// Step k (row block k, from the bottom): every workgroup recomputes
-//   alpha_k = invL_kk^T (z_k - w_k)       (128x128 product against the inverted diagonal tile)
-// block j == k stores it; blocks j < k fold  w_j += L[k-block, j-block]^T alpha_k.
-__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const double *L, long lda, const double *invL, long Npad,
-                                                            const double *Z, long ldz, int P, double *Aout, double *w,
-                                                            int k) {
-    __shared__ double v[GP_TILE];
-    __shared__ double al[GP_TILE];
-    __shared__ double part[256];
+// Blocked by panels of PB = W*128 columns, from the last panel to the first, using the inverted
+// diagonal panels invP_J = L_JJ^-1 (built once per fit on the MFMA GEMM, see api.hip):
+//   alpha_J = invP_J^T (z_J - w_J)                 (panel_solve: one workgroup per 128 outputs)
+//   w_j    += L[J rows, j cols]^T alpha_J, j < J   (panel_update: one workgroup per 128 columns)
+// 2 launches per panel (32 at N = 16384) instead of one per 128-row block; L is streamed once.
+#define PT 1024  // threads of the panel kernels: 128 columns x 8 row groups, 8 independent loads in flight each
+__global__ __launch_bounds__(PT) void panel_solve_kernel(const double *invP, long ldp, int Kp, const double *Z,
+                                                         long ldz, const double *w, long ldw, int P, long off,
+                                                         double *Aout) {
+    __shared__ double part[PT];
+    extern __shared__ double v[];  // Kp
     const int tid = threadIdx.x;
-    const int j = blockIdx.x;  // 0..k
-    const int c = tid & 127, h = tid >> 7;
-    const double *Ik = invL + (long)k * GP_TILE * GP_TILE;
+    const int c = blockIdx.x * GP_TILE + (tid & 127), rg = tid >> 7;
+    // invP lower triangular: only rows r >= first column of this chunk can be non-zero
+    const int r0 = blockIdx.x * GP_TILE;
+    const int per = (Kp - r0) / 8;  // multiple of 16 (Kp - r0 is a multiple of 128)
     for (int p = 0; p < P; ++p) {
-        if (tid < GP_TILE) v[tid] = Z[p * ldz + (long)k * GP_TILE + tid] - w[p * Npad + (long)k * GP_TILE + tid];
+        for (int r = tid; r < Kp; r += PT) v[r] = Z[p * ldz + off + r] - w[p * ldw + off + r];
         __syncthreads();
-        // alpha[c] = sum_r invL[r][c] v[r]; invL lower => r >= c
-        double s = 0.0;
-        for (int r = h * 64; r < h * 64 + 64; ++r) s = fma(Ik[r * GP_TILE + c], v[r], s);
-        part[tid] = s;
+        const double *ip = invP + (long)(r0 + rg * per) * ldp + c;
+        const double *vp = v + r0 + rg * per;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int r = 0; r < per; r += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = ip[(long)(r + u) * ldp];
+            s0 = fma(x[0], vp[r + 0], s0); s1 = fma(x[1], vp[r + 1], s1);
+            s2 = fma(x[2], vp[r + 2], s2); s3 = fma(x[3], vp[r + 3], s3);
+            s0 = fma(x[4], vp[r + 4], s0); s1 = fma(x[5], vp[r + 5], s1);
+            s2 = fma(x[6], vp[r + 6], s2); s3 = fma(x[7], vp[r + 7], s3);
+        }
+        part[tid] = (s0 + s1) + (s2 + s3);
         __syncthreads();
-        if (tid < GP_TILE) al[tid] = part[tid] + part[tid + 128];
+        if (tid < GP_TILE) {
+            double t = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += part[tid + 128 * u];
+            Aout[p * ldz + off + c] = t;
+        }
         __syncthreads();
-        if (j == k) {
-            if (tid < GP_TILE) Aout[p * ldz + (long)k * GP_TILE + tid] = al[tid];
-        } else {
-            const double *Lb = L + (long)k * GP_TILE * lda + (long)j * GP_TILE;
-            double u = 0.0;
-            for (int r = h * 64; r < h * 64 + 64; ++r) u = fma(Lb[(long)r * lda + c], al[r], u);
-            part[tid] = u;
-            __syncthreads();
-            if (tid < GP_TILE) w[p * Npad + (long)j * GP_TILE + tid] += part[tid] + part[tid + 128];
+    }
+}
+__global__ __launch_bounds__(PT) void panel_update_kernel(const double *L, long lda, int Kp, long rowoff,
+                                                          const double *alpha, long ldz, int P, double *w, long ldw) {
+    __shared__ double part[PT];
+    extern __shared__ double al[];  // Kp
+    const int tid = threadIdx.x;
+    const long c = (long)blockIdx.x * GP_TILE + (tid & 127);
+    const int rg = tid >> 7;
+    const int per = Kp / 8;  // multiple of 16
+    const double *Lb = L + (rowoff + (long)rg * per) * lda + c;
+    for (int p = 0; p < P; ++p) {
+        for (int r = tid; r < Kp; r += PT) al[r] = alpha[p * ldz + rowoff + r];
+        __syncthreads();
+        const double *ap = al + rg * per;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int r = 0; r < per; r += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = Lb[(long)(r + u) * lda];
+            s0 = fma(x[0], ap[r + 0], s0); s1 = fma(x[1], ap[r + 1], s1);
+            s2 = fma(x[2], ap[r + 2], s2); s3 = fma(x[3], ap[r + 3], s3);
+            s0 = fma(x[4], ap[r + 4], s0); s1 = fma(x[5], ap[r + 5], s1);
+            s2 = fma(x[6], ap[r + 6], s2); s3 = fma(x[7], ap[r + 7], s3);
+        }
+        part[tid] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (tid < GP_TILE) {
+            double t = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += part[tid + 128 * u];
+            w[p * ldw + c] += t;
         }
         __syncthreads();
     }
@@ -94,14 +135,24 @@ __global__ void zero_kernel(double *p, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
 }
-void launch_trsv_backward(hipStream_t s, const double *L, long lda, const double *invL, long Npad, const double *Z,
-                          long ldz, int P, double *Aout, double *w) {
+// invP: panels of W tiles, each stored as a PB x PB row-major block (PB = W*128) at invP + J*PB*PB
+void launch_trsv_backward(hipStream_t s, const double *L, long lda, const double *invP, int W, long Npad,
+                          const double *Z, long ldz, int P, double *Aout, double *w) {
     const long nw = (long)P * Npad;
     hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w, nw);
     const int nt = (int)(Npad / GP_TILE);
-    for (int k = nt - 1; k >= 0; --k)
-        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k + 1), dim3(256), 0, s, L, lda, invL, Npad, Z, ldz, P, Aout, w,
-                           k);
+    const long PB = (long)W * GP_TILE;
+    const int nJ = (nt + W - 1) / W;
+    for (int J = nJ - 1; J >= 0; --J) {
+        const int J0 = J * W, J1 = std::min(J0 + W, nt);
+        const int Kp = (J1 - J0) * GP_TILE;
+        const long off = (long)J0 * GP_TILE;
+        hipLaunchKernelGGL(panel_solve_kernel, dim3(J1 - J0), dim3(PT), Kp * sizeof(double), s, invP + (long)J * PB * PB,
+                           PB, Kp, Z, ldz, w, Npad, P, off, Aout);
+        if (J0 > 0)
+            hipLaunchKernelGGL(panel_update_kernel, dim3(J0), dim3(PT), Kp * sizeof(double), s, L, lda, Kp, off, Aout,
+                               ldz, P, w, Npad);
+    }
 }
 
 // ---- posterior reductions (posterior.py:277,292-295; gaussian.py:109) --------------------------

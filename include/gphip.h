@@ -152,8 +152,11 @@ int gp_last_phases(gp_t *gp, int cap, const char **names, double *ms, double *fl
  * events around every launch when profiling is on), algorithmic flops.  Reset by gp_profile(gp, 1). */
 int gp_profile(gp_t *gp, int on);
 int gp_gemm_stats(gp_t *gp, int64_t *launches, double *ms, double *flops);
+/* per-launch record of the profiled GEMM launches: output tiles, K (negative: triangular contraction), ms */
+int gp_gemm_trace(gp_t *gp, int cap, int64_t *tiles, int *K, double *ms);
 int gp_synchronize(gp_t *gp);
-/* tunables: "panel_tiles" (outer panel width in 128-tiles), "lookahead" (0/1), "mc_max" */
+/* tunables: "panel_tiles" (outer panel width in 128-tiles), "lookahead" (0/1),
+ * "reserve_cus" (CUs kept free of the trailing update for the look-ahead chain), "mc_max" */
 int gp_set_option(gp_t *gp, const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -23,6 +23,21 @@
 // parked transposed in the unused upper triangle of the LDS tile.
 #include "gphip_internal.h"
 
+#ifdef POTRF_STAMPS
+// diagnostic build only (tools/micro/potrf_bench.hip): cycle stamps of wave 0 into a buffer of their own
+__device__ unsigned long long g_potrf_stamps[64];
+#define STAMP(i)                                                                                  \
+    do {                                                                                          \
+        if (threadIdx.x == 0) {                                                                   \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            g_potrf_stamps[i] = t_;                                                               \
+        }                                                                                         \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 #define TS 130   // LDS pitch of the tile (doubles)
 #define DS 18    // LDS pitch of a 16x16 inverse micro block
 #define DBLK (16 * DS)
@@ -153,6 +168,7 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     double *At = A + (long)t * GP_TILE * lda + (long)t * GP_TILE;
+    STAMP(0);
 
     // load the lower part (whole rows: simpler and coalesced), 16 B per lane
     for (int q = 0; q < 16; ++q) {
@@ -162,6 +178,7 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
         *(double2_t *)(T + r * TS + c2) = v;
     }
     __syncthreads();
+    STAMP(1);
     if (wave == 0) {
         const int fail = potrf16_inv16(T, Dinv, 0, lane);
         if (fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + fail + 1);
@@ -172,7 +189,9 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
     //   stage A  wave 0: row block p+1 of the panel solve;      waves 1..7: row blocks p+2..7
     //   stage B  wave 0: update of block (p+1,p+1), then its factorisation + inverse (the latency chain);
     //            waves 1..7: every other trailing block (i, j), p < j <= i, (i, j) != (p+1, p+1)
+    STAMP(2);
     for (int p = 0; p < 7; ++p) {
+        STAMP(3 + 3 * p);
         {   // stage A: X = T[rb][p] * Dinv[p]^T
             const int rb = p + 1 + wave;
             if (rb < 8) {
@@ -186,6 +205,7 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
             }
         }
         __syncthreads();
+        STAMP(4 + 3 * p);
         if (wave == 0) {
             const int i = p + 1;
             const double *ap = T + (i * 16 + li) * TS + p * 16 + lg;
@@ -198,6 +218,7 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
             for (int r = 0; r < 4; ++r) cp[(4 * r) * TS] = acc[r];
             const int fail = potrf16_inv16(T, Dinv, i, lane);
             if (fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + i * 16 + fail + 1);
+            STAMP(5 + 3 * p);
         } else {
             // blocks (i, j), p+1 <= j <= i <= 7 without (p+1, p+1): enumerate rows i = p+1 .. 7
             const int nb = 7 - p;
@@ -222,6 +243,7 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
         __syncthreads();
     }
 
+    STAMP(24);
     // ---- tile inverse, block column j = wave; Inv[i][j] parked at T[(j16+n)][(i16+m)] = Inv_ij[m][n]
     for (int i = 1; i < 8; ++i) {
         const int j = wave;
@@ -254,6 +276,7 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
         __syncthreads();
     }
 
+    STAMP(25);
     // ---- write back: L (lower incl. diagonal) in place, inverse tile to the workspace
     double *Iv = invL + (long)t * GP_TILE * GP_TILE;
     for (int q = 0; q < 32; ++q) {
@@ -270,6 +293,7 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
             inv = 0.0;
         Iv[r * GP_TILE + c] = inv;
     }
+    STAMP(26);
 }
 
 void launch_potrf_tile(hipStream_t s, double *A, long lda, int t, double *invL, int *info) {

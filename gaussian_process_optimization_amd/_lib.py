@@ -32,6 +32,8 @@ SIGNATURES = [
     ("gp_set_data", ctypes.c_int, [_vp, c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     ("gp_set_params", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_double]),
     ("gp_fit", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
+    ("gp_fit_predict", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
+                                      c_double_p]),
     ("gp_get_alpha", ctypes.c_int, [_vp, c_double_p]),
     ("gp_get_chol", ctypes.c_int, [_vp, c_double_p]),
     ("gp_get_woodbury_inv", ctypes.c_int, [_vp, c_double_p]),
@@ -162,6 +164,16 @@ class Handle(object):
         rc = self.lib.gp_fit(self.h, int(maxtries), ctypes.byref(lml), ctypes.byref(logdet), ctypes.byref(jit))
         check(self.lib, rc, "gp_fit")
         return lml.value, logdet.value, jit.value
+
+    def fit_predict(self, include_noise=True, maxtries=5):
+        """gp_fit + gp_predict on the resident candidates as one pipelined pass."""
+        lml, logdet, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        mean = np.empty((self.M, self.P))
+        var = np.empty((self.M, 1))
+        rc = self.lib.gp_fit_predict(self.h, int(maxtries), int(bool(include_noise)), ctypes.byref(lml),
+                                     ctypes.byref(logdet), ctypes.byref(jit), dptr(mean), dptr(var))
+        check(self.lib, rc, "gp_fit_predict")
+        return (lml.value, logdet.value, jit.value), mean, var
 
     def alpha(self):
         out = np.empty((self.N, self.P))

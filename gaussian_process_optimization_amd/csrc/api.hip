@@ -7,9 +7,13 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <array>
+#include <map>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 // ------------------------------------------------------------------------------------------
@@ -50,6 +54,7 @@ struct gp_ctx {
     hipStream_t s_panel = nullptr; // look-ahead (panel chain) stream: high priority, all CUs
     hipStream_t s_bulk = nullptr;  // trailing-update stream of the look-ahead Cholesky: masked off the reserved CUs
     int bulk_reserved = -1;        // reserved-CU count s_bulk was created with
+    hipStream_t s_inv = nullptr, s_pred = nullptr;  // pipelined candidate solve (gp_fit_predict), low priority
     std::vector<hipEvent_t> la_events;
     // data
     long N = 0, Npad = 0;
@@ -99,7 +104,7 @@ struct gp_ctx {
     double *dDm = nullptr, *dDv = nullptr, *dDacq = nullptr;
     long capD = 0;
     // options
-    int panel_tiles = 8;
+    int panel_tiles = 6;
     int lookahead = 1;
     int reserve_cus = 8;
     long mc_max = 16384;
@@ -109,14 +114,83 @@ struct gp_ctx {
     bool profiling = false;
     std::vector<hipEvent_t> gemm_events;
     std::vector<long> gemm_tiles;
+    std::map<std::array<int, 5>, short *> tile_lists;  // cached L2-friendly tile orders (device)
+    int supertile = 0;
+    int small_below = 1400;  // launches with fewer 128-tiles than this use 64x64 workgroup tiles
+    int stagger = 3;  // see gemm.hip: odd-slot workgroups start 3 * 1024 cycles late (+1.5 % measured)
+    int pipe_start_pct = 0;   // gp_fit_predict: candidate stages start once this share of the panels is factored
     std::vector<int> gemm_K;
     size_t gemm_ev_used = 0;
     long gemm_launches = 0;
-    double gemm_flops = 0.0;
+    double gemm_flops = 0.0;      // flops of the event-bracketed launches
+    double gemm_flops_all = 0.0;  // flops of every GEMM launch since gp_profile(1)
+    long profile_min_tiles = 1024;
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
 };
+
+static int ensure_bulk_stream(gp_ctx *g);
+static hipEvent_t la_event(gp_ctx *g, size_t i);
+
+// One set of HIP streams per device for the whole process, created once in a fixed order and never destroyed.
+// Hardware queues are dealt over the command processor's pipes in creation order, and two queues on one pipe do
+// not overlap (a 6000-workgroup dispatch holds the pipe until its last workgroup is issued).  Measured: a context
+// created after an earlier one was closed, or a re-created bulk stream, put the chain and the trailing update on
+// one pipe and the factorisation went from 34 to 45 ms.  Order here: main, chain, bulk, inverse, candidates
+// -> pipes 0,1,2,3,0.
+struct DevStreams {
+    hipStream_t s = nullptr, panel = nullptr, bulk = nullptr, inv = nullptr, pred = nullptr;
+    int reserved = -1;
+};
+static std::mutex g_ds_mu;
+static std::map<int, DevStreams> g_ds;
+
+static int make_bulk_stream(int device, int reserve, hipStream_t *out) {
+    hipDeviceProp_t pr;
+    HIPCHK(hipGetDeviceProperties(&pr, device));
+    const int ncu = pr.multiProcessorCount;
+    const int words = (ncu + 31) / 32;
+    std::vector<uint32_t> mask(words, 0xffffffffu);
+    // CU bits are dealt round-robin over the XCDs (measured: tools/micro/cumask.hip), so clearing the
+    // lowest R bits reserves R/8 CUs on every XCD.
+    for (int i = 0; i < reserve && i < ncu - 8; ++i) mask[i / 32] &= ~(1u << (i % 32));  // reserve may be large (half the chip)
+    if (reserve > 0) {
+        hipError_t e = hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data());
+        if (e != hipSuccess) return fail(GP_ERR_HIP, "hipExtStreamCreateWithCUMask -> %s", hipGetErrorString(e));
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    }
+    return 0;
+}
+
+static int get_streams(int device, int reserve, DevStreams *out) {
+    std::lock_guard<std::mutex> lk(g_ds_mu);
+    if (const char *e = getenv("GPHIP_RESERVE_CUS")) reserve = std::max(0, std::min(64, atoi(e)));
+    DevStreams &d = g_ds[device];
+    if (!d.s) {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(hipStreamCreateWithPriority(&d.s, hipStreamNonBlocking, lo));
+        HIPCHK(hipStreamCreateWithPriority(&d.panel, hipStreamNonBlocking, hi));
+        int rc = make_bulk_stream(device, reserve, &d.bulk);
+        if (rc) return rc;
+        d.reserved = reserve;
+        HIPCHK(hipStreamCreateWithPriority(&d.inv, hipStreamNonBlocking, lo));
+        // the pipelined candidate solve launches thousands of workgroups too: keep it off the reserved CUs as well,
+        // or the chain's diagonal-tile workgroup (which needs an EMPTY CU) waits for a whole candidate update
+        {
+            int rp = reserve;
+            if (const char *e = getenv("GPHIP_PRED_RESERVE")) rp = atoi(e);
+            rc = make_bulk_stream(device, rp, &d.pred);
+            if (rc) return rc;
+        }
+    }
+    // never re-created: the replacement queue lands on another command-processor pipe (creation order), and
+    // when that is the chain stream's pipe the two can no longer overlap
+    *out = d;
+    return 0;
+}
 
 static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
 
@@ -145,7 +219,10 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
     const long n = tileset_count(ts) * o.batch;
     if (n <= 0 || K <= 0) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g->profiling) {
+    // events only around the launches that carry the flops (>= 1024 output tiles): bracketing every one of the
+    // ~700 small launches of an iteration stalls the latency chain (34 -> 53 ms per factorisation, measured)
+    const bool timed = g->profiling && n >= g->profile_min_tiles;
+    if (timed) {
         if (g->gemm_ev_used + 2 > g->gemm_events.size()) {
             hipEvent_t a, b;
             hipEventCreate(&a);
@@ -159,10 +236,36 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
         g->gemm_tiles.push_back(n);
         g->gemm_K.push_back((o.k_tri || o.k_end_tri) ? -K : K);
     }
-    launch_gemm_nt(s, mode, C, ldc, A, lda, B, ldb, b_mul, K, ts, o);
-    if (g->profiling) hipEventRecord(e1, s);
-    g->gemm_launches++;
-    g->gemm_flops += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n * ((o.k_tri || o.k_end_tri) ? 0.5 : 1.0);
+    GemmOpt oo = o;
+    if (n >= 1024 && !oo.stagger) oo.stagger = g->stagger;
+    // short launches (the factorisation's latency chain, the uneven triangular-K products) run as 64x64 work units
+    if (g->small_below > 0 && n < g->small_below && !oo.inplace) oo.small = 1;
+    if (g->supertile > 1 && !o.tile_list && !o.k_end_tri && o.batch == 1 && tileset_count(ts) >= 2048) {
+        const std::array<int, 5> key{ts.r0, ts.r1, ts.c0, ts.c1, ts.tri};
+        auto it = g->tile_lists.find(key);
+        if (it == g->tile_lists.end()) {
+            std::vector<short> l = build_tile_list(ts, g->supertile);
+            short *d = nullptr;
+            if (hipMalloc((void **)&d, l.size() * sizeof(short)) == hipSuccess) {
+                hipMemcpy(d, l.data(), l.size() * sizeof(short), hipMemcpyHostToDevice);
+                it = g->tile_lists.emplace(key, d).first;
+            }
+        }
+        if (it != g->tile_lists.end()) oo.tile_list = it->second;
+    }
+    launch_gemm_nt(s, mode, C, ldc, A, lda, B, ldb, b_mul, K, ts, oo);
+    if (timed) {
+        hipEventRecord(e1, s);
+        g->gemm_launches++;
+        g->gemm_flops += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n * ((o.k_tri || o.k_end_tri) ? 0.5 : 1.0);
+    }
+    g->gemm_flops_all += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n * ((o.k_tri || o.k_end_tri) ? 0.5 : 1.0);
+}
+
+static inline GemmOpt inplace_opt() {
+    GemmOpt o;
+    o.inplace = 1;
+    return o;
 }
 
 // ---- memory helpers -----------------------------------------------------------------------------
@@ -215,10 +318,20 @@ int gp_create(gp_t **out, int device) {
     gp_ctx *g = new gp_ctx();
     g->device = device;
     for (int i = 0; i < MAX_PHASES; ++i) g->phases[i].used = false;
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);
-    HIPCHK(hipStreamCreateWithPriority(&g->s, hipStreamNonBlocking, lo));
-    HIPCHK(hipStreamCreateWithPriority(&g->s_panel, hipStreamNonBlocking, hi));
+    {
+        DevStreams d;
+        int rcs = get_streams(device, g->reserve_cus, &d);
+        if (rcs) {
+            delete g;
+            return rcs;
+        }
+        g->s = d.s;
+        g->s_panel = d.panel;
+        g->s_bulk = d.bulk;
+        g->bulk_reserved = d.reserved;
+        g->s_inv = d.inv;
+        g->s_pred = d.pred;
+    }
     HIPCHK(hipMalloc((void **)&g->dInfo, sizeof(int) * 4));
     HIPCHK(hipMalloc((void **)&g->dScal, sizeof(double) * 512));
     HIPCHK(hipMalloc((void **)&g->dRedV, sizeof(double) * 512));
@@ -244,9 +357,8 @@ int gp_destroy(gp_t *g) {
             hipEventDestroy(g->phases[i].e1);
         }
     for (hipEvent_t e : g->gemm_events) hipEventDestroy(e);
-    if (g->s) hipStreamDestroy(g->s);
-    if (g->s_panel) hipStreamDestroy(g->s_panel);
-    if (g->s_bulk) hipStreamDestroy(g->s_bulk);
+    for (auto &kv : g->tile_lists) hipFree(kv.second);
+    // streams belong to the per-device set shared by every context of the process
     for (hipEvent_t e : g->la_events) hipEventDestroy(e);
     delete g;
     return 0;
@@ -259,9 +371,20 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->panel_tiles = (int)value;
     } else if (!strcmp(name, "lookahead")) {
         g->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "pipe_start_pct")) {
+        if (value < 0 || value > 100) return fail(GP_ERR_ARG, "pipe_start_pct out of range");
+        g->pipe_start_pct = (int)value;
+    } else if (!strcmp(name, "small_below")) {
+        g->small_below = (int)value;
+    } else if (!strcmp(name, "stagger")) {
+        g->stagger = (int)value;
+    } else if (!strcmp(name, "supertile")) {
+        if (value < 0 || value > 64) return fail(GP_ERR_ARG, "supertile out of range");
+        g->supertile = (int)value;
     } else if (!strcmp(name, "reserve_cus")) {
-        if (value < 0 || value > 64) return fail(GP_ERR_ARG, "reserve_cus out of range");
-        g->reserve_cus = (int)value;
+        if (value != g->bulk_reserved)
+            return fail(GP_ERR_ARG, "reserve_cus is fixed when the device's streams are created (%d); set GPHIP_RESERVE_CUS "
+                                    "before the first gp_create", g->bulk_reserved);
     } else if (!strcmp(name, "mc_max")) {
         if (value < GP_TILE) return fail(GP_ERR_ARG, "mc_max < 128");
         g->mc_max = round_up(value, GP_TILE);
@@ -275,6 +398,8 @@ int gp_synchronize(gp_t *g) {
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(hipStreamSynchronize(g->s_panel));
     if (g->s_bulk) HIPCHK(hipStreamSynchronize(g->s_bulk));
+    if (g->s_inv) HIPCHK(hipStreamSynchronize(g->s_inv));
+    if (g->s_pred) HIPCHK(hipStreamSynchronize(g->s_pred));
     HIPCHK(hipStreamSynchronize(g->s));
     return 0;
 }
@@ -354,7 +479,7 @@ static void factor(gp_ctx *g) {
             launch_potrf_tile(s, A, lda, j, g->dInvL, g->dInfo);
             // panel solve: A[i, j] <- A[i, j] * inv(L_jj)^T for the row tiles below (and the RHS tile)
             gemm(g, s, 0, A, lda, A + (long)j * GP_TILE, lda, g->dInvL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0,
-                 GP_TILE, TileSet{j + 1, R1, j, j + 1, 0});
+                 GP_TILE, TileSet{j + 1, R1, j, j + 1, 0}, inplace_opt());
             // update of the remaining columns of this panel (K = 128)
             if (j + 1 < J1)
                 gemm(g, s, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE,
@@ -367,50 +492,36 @@ static void factor(gp_ctx *g) {
     }
 }
 
-// ---- the same factorisation with one panel of look-ahead on three streams ----------------------------
-// s_panel (high priority, every CU): the latency chain of panel J -- potrf tile, panel solve, in-panel
-//          updates -- then the update of panel J+1's columns with panel J (so that chain J+1 can start);
-// s_bulk  (masked off `reserve_cus` CUs, which therefore stay free for the chain's single-workgroup potrf
-//          kernel whose 148 KB of LDS needs an otherwise empty CU): the update of every column right of
-//          panel J+1 with panel J -- the dense contraction, >90 % of the flops;
-// s       : everything before and after.
-// Ordering: bulk(J) after chain(J); look-ahead update(J) after bulk(J-1) (both touch panel J+1's columns);
-// bulk(J) after bulk(J-1) (stream order).  Column sets of concurrent kernels are disjoint by construction.
-static int ensure_bulk_stream(gp_ctx *g) {
-    if (g->s_bulk && g->bulk_reserved == g->reserve_cus) return 0;
-    if (g->s_bulk) {
-        hipStreamSynchronize(g->s_bulk);
-        hipStreamDestroy(g->s_bulk);
-        g->s_bulk = nullptr;
+// Pipelined candidate solve (gp_fit_predict): as soon as panel J of L is final (chain(J) done), two more
+// streams run, behind the factorisation and at low priority,
+//   s_inv : invP_J = L_JJ^-1 (the per-panel build of ensure_panel_inv),
+//   s_pred: S[:, J] = T[:, J] invP_J^T ;  T[:, > J] -= S[:, J] L[> J, J]^T
+// so that the candidates' N^2 M flops fill the CUs the latency chain of the late panels leaves idle.
+struct PredPipe {
+    bool on = false;
+    int mt = 0;          // candidate row tiles
+    double *T = nullptr, *S = nullptr;
+};
+
+static void build_panel_inv_one(gp_ctx *g, hipStream_t s, int J, int W, int nt) {
+    const long lda = g->Npad;
+    const long PB = (long)W * GP_TILE;
+    const int J0 = J * W, Wp = std::min(W, nt - J0);
+    double *Wb = g->dInvPw + (long)J * PB * PB;
+    const double *Lb = g->dA + (long)J * (PB * lda + PB);
+    const double *Ib = g->dInvL + (long)J0 * GP_TILE * GP_TILE;
+    launch_set_identity_blocks(s, Wb, PB, 1);
+    for (int b = 0; b < Wp; ++b) {
+        gemm(g, s, 0, Wb, PB, Wb + (long)b * GP_TILE, PB, Ib + (long)b * GP_TILE * GP_TILE, GP_TILE, 0, GP_TILE,
+             TileSet{0, b + 1, b, b + 1, 0}, inplace_opt());
+        if (b + 1 < Wp)
+            gemm(g, s, 1, Wb, PB, Wb + (long)b * GP_TILE, PB, Lb + (long)b * GP_TILE, lda, 1, GP_TILE,
+                 TileSet{0, b + 1, b + 1, Wp, 0});
     }
-    hipDeviceProp_t pr;
-    HIPCHK(hipGetDeviceProperties(&pr, g->device));
-    const int ncu = pr.multiProcessorCount;
-    const int words = (ncu + 31) / 32;
-    std::vector<uint32_t> mask(words, 0xffffffffu);
-    // CU bits are dealt round-robin over the XCDs (measured: tools/micro/cumask.hip), so clearing the
-    // lowest R bits reserves R/8 CUs on every XCD.
-    for (int i = 0; i < g->reserve_cus && i < ncu - 8; ++i) mask[i / 32] &= ~(1u << (i % 32));
-    if (g->reserve_cus > 0) {
-        hipError_t e = hipExtStreamCreateWithCUMask(&g->s_bulk, (uint32_t)words, mask.data());
-        if (e != hipSuccess) return fail(GP_ERR_HIP, "hipExtStreamCreateWithCUMask -> %s", hipGetErrorString(e));
-    } else {
-        HIPCHK(hipStreamCreateWithFlags(&g->s_bulk, hipStreamNonBlocking));
-    }
-    g->bulk_reserved = g->reserve_cus;
-    return 0;
+    launch_transpose_blocks(s, g->dInvP + (long)J * PB * PB, Wb, PB, 1);
 }
 
-static hipEvent_t la_event(gp_ctx *g, size_t i) {
-    while (g->la_events.size() <= i) {
-        hipEvent_t e;
-        hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        g->la_events.push_back(e);
-    }
-    return g->la_events[i];
-}
-
-static int factor_lookahead(gp_ctx *g) {
+static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     int rc;
     if ((rc = ensure_bulk_stream(g))) return rc;
     const long lda = g->Npad;
@@ -425,30 +536,63 @@ static int factor_lookahead(gp_ctx *g) {
     hipEventRecord(e0, g->s);
     hipStreamWaitEvent(sp, e0, 0);
     hipStreamWaitEvent(sb, e0, 0);
-    // events: 1 + 2J = chain(J) done, 2 + 2J = bulk(J) done
+    const long PB = (long)W * GP_TILE;
+    if (pp.on) {
+        hipStreamWaitEvent(g->s_inv, e0, 0);
+        hipStreamWaitEvent(g->s_pred, e0, 0);
+    }
+    // events: 1 + 2J = chain(J) done, 2 + 2J = bulk(J) done; 1000 + J = invP_J built
+    int next_pred = 0;
+    const int pred_start = std::min(nJ - 1, nJ * g->pipe_start_pct / 100);
     for (int J = 0; J < nJ; ++J) {
         const int J0 = J * W, J1 = std::min(J0 + W, nt), J2 = std::min(J1 + W, nt);
         for (int j = J0; j < J1; ++j) {
             launch_potrf_tile(sp, A, lda, j, g->dInvL, g->dInfo);
             gemm(g, sp, 0, A, lda, A + (long)j * GP_TILE, lda, g->dInvL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0,
-                 GP_TILE, TileSet{j + 1, R1, j, j + 1, 0});
+                 GP_TILE, TileSet{j + 1, R1, j, j + 1, 0}, inplace_opt());
             if (j + 1 < J1)
                 gemm(g, sp, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE,
                      TileSet{0, R1, j + 1, J1, 1});
         }
-        if (J1 >= nt) break;
         hipEvent_t eF = la_event(g, 1 + 2 * J);
         hipEventRecord(eF, sp);
         const int K = (J1 - J0) * GP_TILE;
+        if (pp.on) {
+            hipStreamWaitEvent(g->s_inv, eF, 0);
+            build_panel_inv_one(g, g->s_inv, J, W, nt);
+            hipEventRecord(la_event(g, 1000 + J), g->s_inv);
+            // Two concurrent MFMA-bound launches run slower than one after the other (measured 51 vs 63 TFLOP/s:
+            // they evict each other's operand panels from L2), so the candidate stages are held back until the
+            // factorisation turns latency-bound (panel >= pred_start) and only then released, in order.
+            if (J >= pred_start) {
+                for (; next_pred <= J; ++next_pred) {
+                    const int Q = next_pred, Q0 = Q * W, Q1 = std::min(Q0 + W, nt);
+                    const int KQ = (Q1 - Q0) * GP_TILE;
+                    hipStreamWaitEvent(g->s_pred, la_event(g, 1 + 2 * J), 0);
+                    hipStreamWaitEvent(g->s_pred, la_event(g, 1000 + Q), 0);
+                    GemmOpt o;
+                    o.k_end_tri = 1;
+                    o.b_sub = Q0;
+                    gemm(g, g->s_pred, 0, pp.S, g->Npad, pp.T + (long)Q0 * GP_TILE, g->Npad, g->dInvP + (long)Q * PB * PB,
+                         PB, 1, KQ, TileSet{0, pp.mt, Q0, Q1, 0}, o);
+                    if (Q1 < nt)
+                        gemm(g, g->s_pred, 1, pp.T, g->Npad, pp.S + (long)Q0 * GP_TILE, g->Npad, A + (long)Q0 * GP_TILE, lda,
+                             1, KQ, TileSet{0, pp.mt, Q1, nt, 0});
+                }
+            }
+        }
+        if (J1 >= nt) break;
+        // the look-ahead update is on the critical path: enqueue it before the trailing update so that its
+        // workgroups reach the dispatcher first once bulk(J-1) has drained
+        if (J >= 1) hipStreamWaitEvent(sp, la_event(g, 2 + 2 * (J - 1)), 0);
+        gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
+             TileSet{0, R1, J1, J2, 1});
         if (J2 < nt) {
             hipStreamWaitEvent(sb, eF, 0);
             gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
                  TileSet{0, R1, J2, nt, 1});
             hipEventRecord(la_event(g, 2 + 2 * J), sb);
         }
-        if (J >= 1) hipStreamWaitEvent(sp, la_event(g, 2 + 2 * (J - 1)), 0);
-        gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
-             TileSet{0, R1, J1, J2, 1});
     }
     // join
     hipEvent_t ep = la_event(g, 1 + 2 * nJ + 1), eb = la_event(g, 1 + 2 * nJ + 2);
@@ -456,7 +600,41 @@ static int factor_lookahead(gp_ctx *g) {
     hipEventRecord(eb, sb);
     hipStreamWaitEvent(g->s, ep, 0);
     hipStreamWaitEvent(g->s, eb, 0);
+    if (pp.on) {
+        hipEvent_t eq = la_event(g, 1 + 2 * nJ + 3), ei = la_event(g, 1 + 2 * nJ + 4);
+        hipEventRecord(eq, g->s_pred);
+        hipEventRecord(ei, g->s_inv);
+        hipStreamWaitEvent(g->s, eq, 0);
+        hipStreamWaitEvent(g->s, ei, 0);
+    }
     return 0;
+}
+
+// ---- the same factorisation with one panel of look-ahead on three streams ----------------------------
+// s_panel (high priority, every CU): the latency chain of panel J -- potrf tile, panel solve, in-panel
+//          updates -- then the update of panel J+1's columns with panel J (so that chain J+1 can start);
+// s_bulk  (masked off `reserve_cus` CUs, which therefore stay free for the chain's single-workgroup potrf
+//          kernel whose 148 KB of LDS needs an otherwise empty CU): the update of every column right of
+//          panel J+1 with panel J -- the dense contraction, >90 % of the flops;
+// s       : everything before and after.
+// Ordering: bulk(J) after chain(J); look-ahead update(J) after bulk(J-1) (both touch panel J+1's columns);
+// bulk(J) after bulk(J-1) (stream order).  Column sets of concurrent kernels are disjoint by construction.
+static int ensure_bulk_stream(gp_ctx *g) {
+    DevStreams d;
+    int rc = get_streams(g->device, g->reserve_cus, &d);
+    if (rc) return rc;
+    g->s_bulk = d.bulk;
+    g->bulk_reserved = d.reserved;
+    return 0;
+}
+
+static hipEvent_t la_event(gp_ctx *g, size_t i) {
+    while (g->la_events.size() <= i) {
+        hipEvent_t e;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        g->la_events.push_back(e);
+    }
+    return g->la_events[i];
 }
 
 // ---- inverted diagonal panels ---------------------------------------------------------------------
@@ -489,11 +667,13 @@ static int ensure_panel_inv(gp_ctx *g) {
         for (int b = 0; b < Wp; ++b) {
             GemmOpt o;
             o.batch = batch;
+            o.inplace = 1;
             o.sC = o.sA = PB * PB;
             o.sB = (long)W * GP_TILE * GP_TILE;
             gemm(g, s, 0, Wb, PB, Wb + (long)b * GP_TILE, PB, Ib + (long)b * GP_TILE * GP_TILE, GP_TILE, 0, GP_TILE,
                  TileSet{0, b + 1, b, b + 1, 0}, o);
             if (b + 1 < Wp) {
+                o.inplace = 0;
                 o.sB = PB * lda + PB;
                 gemm(g, s, 1, Wb, PB, Wb + (long)b * GP_TILE, PB, Lb + (long)b * GP_TILE, lda, 1, GP_TILE,
                      TileSet{0, b + 1, b + 1, Wp, 0}, o);
@@ -549,12 +729,32 @@ __global__ void dot_ay_kernel(const double *alpha, long lda_, const double *Y, l
     }
 }
 
-int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_used) {
-    if (!g) return fail(GP_ERR_ARG, "null gp");
-    if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit");
+static int ensure_out(gp_ctx *g);
+
+// Shared body of gp_fit and gp_fit_predict.  pipe != 0: the candidate solve of the resident candidates is
+// pipelined behind the factorisation (PredPipe above) and the posterior reductions are appended.
+static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     HIPCHK(hipSetDevice(g->device));
     const long N = g->N, Npad = g->Npad, lda = g->Npad;
     const int P = g->P;
+    const int nt_ = (int)(Npad / GP_TILE);
+    const long mcpad = pipe ? round_up(g->M, GP_TILE) : 0;
+    PredPipe pp;
+    if (pipe) {
+        int rc;
+        const int W = std::min(g->panel_tiles, nt_);
+        const long PB = (long)W * GP_TILE;
+        const int nJ = (nt_ + W - 1) / W;
+        if ((rc = ensure_out(g))) return rc;
+        if ((rc = dev_realloc(&g->dT, &g->capT, mcpad * Npad))) return rc;
+        if ((rc = dev_realloc(&g->dT2, &g->capT2, mcpad * Npad))) return rc;
+        if ((rc = dev_realloc(&g->dInvP, &g->capInvP, (long)nJ * PB * PB))) return rc;
+        if ((rc = dev_realloc(&g->dInvPw, &g->capInvPw, (long)nJ * PB * PB))) return rc;
+        pp.on = true;
+        pp.mt = (int)(mcpad / GP_TILE);
+        pp.T = g->dT;
+        pp.S = g->dT2;
+    }
     const double diag_add = g->noise + 1e-8;  // exact_gaussian_inference.py:56
     const double diag0 = g->kp.variance + diag_add;
     g->nphases = 0;
@@ -575,12 +775,21 @@ int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_us
         launch_set_rhs(g->s, g->dA, lda, g->dY, N, Npad, P);
         phase_end(g, ph);
         HIPCHK(hipMemsetAsync(g->dInfo, 0, sizeof(int) * 4, g->s));
-        ph = phase_begin(g, "cholesky", (double)N * N * N / 3.0, 0.0);
-        if (g->lookahead && Npad / GP_TILE > g->panel_tiles) {
-            int rcf = factor_lookahead(g);
+        if (pipe) {
+            ph = phase_begin(g, "cross_k", 0.0, 8.0 * (double)(N + g->M) * g->D + 8.0 * (double)N * g->M);
+            launch_cross_k(g->s, g->dT, Npad, g->dXs, g->M, mcpad, g->dX, N, Npad, g->kp);
+            phase_end(g, ph);
+            ph = phase_begin(g, "cholesky+cand_solve", (double)N * N * N / 3.0 + (double)N * N * g->M, 0.0);
+            int rcf = factor_lookahead(g, pp);
             if (rcf) return rcf;
         } else {
-            factor(g);
+            ph = phase_begin(g, "cholesky", (double)N * N * N / 3.0, 0.0);
+            if (g->lookahead && Npad / GP_TILE > g->panel_tiles) {
+                int rcf = factor_lookahead(g);
+                if (rcf) return rcf;
+            } else {
+                factor(g);
+            }
         }
         phase_end(g, ph);
         HIPCHK(hipMemcpyAsync(&info, g->dInfo, sizeof(int), hipMemcpyDeviceToHost, g->s));
@@ -600,6 +809,10 @@ int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_us
         g->nphases = 0;
     }
     g->jitter = jitter;
+    if (pipe) {  // every inverted panel was built by the pipeline
+        g->invp_W = std::min(g->panel_tiles, nt_);
+        g->invp_valid = true;
+    }
 
     int ph = phase_begin(g, "alpha_lml", 2.0 * (double)N * N * P, 8.0 * (double)N * N / 2);
     launch_logdet(g->s, g->dA, lda, N, g->dScal);
@@ -610,6 +823,12 @@ int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_us
     launch_trsv_backward(g->s, g->dA, lda, g->dInvP, g->invp_W, Npad, g->dA + Npad * lda, lda, P, g->dAlpha, g->dW);
     hipLaunchKernelGGL(dot_ay_kernel, dim3(P), dim3(1024), 0, g->s, g->dAlpha, Npad, g->dY, N, P, g->dScal + 8);
     phase_end(g, ph);
+    if (pipe) {
+        ph = phase_begin(g, "reduce", 0.0, 8.0 * (double)N * g->M);
+        launch_predict_reduce(g->s, g->dT2, Npad, g->M, N, g->dA + Npad * Npad, Npad, P, g->kp.variance,
+                              include_noise ? g->noise : 0.0, g->dMean, g->dVar);
+        phase_end(g, ph);
+    }
     std::vector<double> sc(8 + P);
     HIPCHK(hipMemcpyAsync(sc.data(), g->dScal, sizeof(double) * (8 + P), hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipStreamSynchronize(g->s));
@@ -619,9 +838,51 @@ int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_us
     const double log_2_pi = std::log(2.0 * M_PI);
     g->lml = 0.5 * (-(double)N * P * log_2_pi - P * g->logdet - fit);  // exact_gaussian_inference.py:62
     g->fitted = true;
+    if (pipe) {
+        g->predicted = true;
+        g->predicted_noise = include_noise ? 1 : 0;
+    }
+    return 0;
+}
+
+int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_used) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit");
+    int rc = fit_impl(g, maxtries, 0, 0);
+    if (rc) return rc;
     if (lml) *lml = g->lml;
     if (logdet) *logdet = g->logdet;
     if (jitter_used) *jitter_used = g->jitter;
+    return 0;
+}
+
+static int run_predict(gp_ctx *g, int include_noise);
+
+// gp_fit followed by gp_predict on the resident candidates, as ONE pipelined pass (the BO loop always runs
+// them back to back: GPyOpt/GPyOpt/core/bo.py:236-254 then acquisitions/base.py:33-39).  Results are those of
+// the two separate calls; the candidate solve merely overlaps the factorisation's latency-bound phases.
+int gp_fit_predict(gp_t *g, int maxtries, int include_noise, double *lml, double *logdet, double *jitter_used,
+                   double *mean, double *var) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit_predict");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    HIPCHK(hipSetDevice(g->device));
+    const int nt = (int)(g->Npad / GP_TILE);
+    const bool can_pipe = g->lookahead && nt > g->panel_tiles && round_up(g->M, GP_TILE) <= g->mc_max;
+    int rc;
+    if (can_pipe) {
+        if ((rc = fit_impl(g, maxtries, 1, include_noise))) return rc;
+    } else {
+        if ((rc = fit_impl(g, maxtries, 0, 0))) return rc;
+        if ((rc = ensure_out(g))) return rc;
+        if ((rc = run_predict(g, include_noise))) return rc;
+    }
+    if (lml) *lml = g->lml;
+    if (logdet) *logdet = g->logdet;
+    if (jitter_used) *jitter_used = g->jitter;
+    if (mean) HIPCHK(hipMemcpyAsync(mean, g->dMean, sizeof(double) * g->M * g->P, hipMemcpyDeviceToHost, g->s));
+    if (var) HIPCHK(hipMemcpyAsync(var, g->dVar, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
     return 0;
 }
 
@@ -824,6 +1085,7 @@ int gp_profile(gp_t *g, int on) {
     g->gemm_K.clear();
     g->gemm_launches = 0;
     g->gemm_flops = 0.0;
+    g->gemm_flops_all = 0.0;
     return 0;
 }
 
@@ -832,6 +1094,8 @@ int gp_gemm_stats(gp_t *g, int64_t *launches, double *ms, double *flops) {
     hipSetDevice(g->device);
     hipStreamSynchronize(g->s_panel);
     if (g->s_bulk) hipStreamSynchronize(g->s_bulk);
+    if (g->s_inv) hipStreamSynchronize(g->s_inv);
+    if (g->s_pred) hipStreamSynchronize(g->s_pred);
     hipStreamSynchronize(g->s);
     double tot = 0.0;
     for (size_t i = 0; i + 1 < g->gemm_ev_used; i += 2) {
@@ -849,6 +1113,8 @@ int gp_gemm_trace(gp_t *g, int cap, int64_t *tiles, int *K, double *ms) {
     hipSetDevice(g->device);
     hipStreamSynchronize(g->s_panel);
     if (g->s_bulk) hipStreamSynchronize(g->s_bulk);
+    if (g->s_inv) hipStreamSynchronize(g->s_inv);
+    if (g->s_pred) hipStreamSynchronize(g->s_pred);
     hipStreamSynchronize(g->s);
     int n = (int)std::min<size_t>((size_t)cap, g->gemm_tiles.size());
     for (int i = 0; i < n; ++i) {

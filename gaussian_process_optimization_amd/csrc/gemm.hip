@@ -58,12 +58,15 @@ struct GemmArgs {
     int b_sub;      // B row tile = (tc - b_sub) * b_mul
     long sC, sA, sB;  // batch strides (elements) applied with blockIdx.y
     const short *tile_list;  // optional explicit (row tile, col tile) order (L2-friendly super-tiles)
+    int stagger;             // > 0: odd-slot workgroups start stagger * 1024 cycles late
 };
 
 __device__ __forceinline__ void tile_from_linear(long t, const GemmArgs &a, int &i, int &c) {
     if (!a.tri) {
         int nr = a.r1 - a.r0;
-        c = a.c0 + (int)(t / nr);
+        c = (int)(t / nr);
+        // triangular-K products: the last column tiles contract the longest K, start them first
+        c = a.k_end_tri ? a.c1 - 1 - c : a.c0 + c;
         i = a.r0 + (int)(t % nr);
         return;
     }
@@ -85,15 +88,27 @@ __device__ __forceinline__ void tile_from_linear(long t, const GemmArgs &a, int 
     i = c + (int)(t - S);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) double smem[2 * 2 * GP_TILE * LSTR];  // [buf][A|B][128][18]
+// BT = block tile edge: 128 (throughput: 4x4 MFMA accumulators per wave, 2 workgroups/CU) or 64 (latency:
+// 2x2 accumulators per wave, a quarter of the work per workgroup and up to 4 workgroups/CU -- used for the
+// short launches of the factorisation's latency chain and the uneven triangular-K products).  With BT = 64
+// every 128x128 tile of the tile set is computed by four workgroups.
+template <int MODE, int BT>
+__global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_nt_kernel(GemmArgs a) {
+    constexpr int MT = BT / 32;            // 16x16 MFMA tiles per wave along m and n
+    constexpr int WT = BT / 2;             // wave tile edge
+    constexpr int LQ = BT / 32;            // 16-byte staging loads per thread and operand
+    __shared__ __attribute__((aligned(16))) double smem[2 * 2 * BT * LSTR];  // [buf][A|B][BT][18]
 
     // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
     // run of the tile list so that neighbouring tiles (same A row panel) hit the same L2.
     const long nwg = gridDim.x, bid = blockIdx.x;
     const long q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const long wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    long wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    int sub = 0;
+    if (BT == 64) {
+        sub = (int)(wg & 3);
+        wg >>= 2;
+    }
 
     int ti, tc;
     if (a.tile_list) {
@@ -105,6 +120,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     // the triangular decode goes through a VALU sqrt: tell the compiler the result is wave-uniform
     ti = __builtin_amdgcn_readfirstlane(ti);
     tc = __builtin_amdgcn_readfirstlane(tc);
+    const int sr = (BT == 64) ? (sub >> 1) * 64 : 0;  // row / column offset of this workgroup inside the 128-tile
+    const int sc = (BT == 64) ? (sub & 1) * 64 : 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,10 +132,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     const long z = blockIdx.y;
     const int kstart = a.k_tri ? ti * GP_TILE : 0;
     const int kend = a.k_end_tri ? (tc - a.b_sub + 1) * GP_TILE : a.K;
-    const double *Ag = a.A + z * a.sA + (long)ti * GP_TILE * a.lda + kstart;
-    const double *Bg = a.B + z * a.sB + (long)(tc - a.b_sub) * a.b_mul * GP_TILE * a.ldb + kstart;
+    const double *Ag = a.A + z * a.sA + ((long)ti * GP_TILE + sr) * a.lda + kstart;
+    const double *Bg = a.B + z * a.sB + ((long)(tc - a.b_sub) * a.b_mul * GP_TILE + sc) * a.ldb + kstart;
 
-    // staging map: 128 rows x 8 chunks(16 B); thread handles rows (tid>>3) + 32q, chunk tid&7
+    // staging map: BT rows x 8 chunks(16 B); thread handles rows (tid>>3) + 32q, chunk tid&7
     const int srow = tid >> 3, sch = (tid & 7) * 2;
     const double *ap = Ag + (long)srow * a.lda + sch;
     const double *bp = Bg + (long)srow * a.ldb + sch;
@@ -126,48 +143,63 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     const int soff = srow * LSTR + sch;
 
     // accumulator element r of tile (m,n) is C[row = lg + 4r][col = li] of that 16x16 tile
-    double *Cw = a.C + z * a.sC + ((long)ti * GP_TILE + wm * 64) * a.ldc + (long)tc * GP_TILE + wn * 64;  // uniform
+    double *Cw = a.C + z * a.sC + ((long)ti * GP_TILE + sr + wm * WT) * a.ldc + (long)tc * GP_TILE + sc + wn * WT;  // uniform
     const unsigned cbyte = (unsigned)(lg * (int)a.ldc + li) * 8u;  // lane part of the address, bytes
-    const unsigned crow = (unsigned)a.ldc * 8u;                    // row stride, bytes (wave tile spans 64 rows: < 2^31)
+    const unsigned crow = (unsigned)a.ldc * 8u;                    // row stride, bytes (wave tile spans <= 64 rows: < 2^31)
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(Cw, 0, 0x7fffffff, 0x00020000);
-    double4_t acc[4][4];
+    double4_t acc[MT][MT];
     if (MODE == 1) {
         // C -= A B^T: the old C rides in as the MFMA C operand (A negated by the f64 MFMA neg modifier), so
         // its HBM read overlaps the first operand-tile loads and the epilogue is stores only.
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < MT; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     acc[m][n][r] = buf_load_f64(crs, cbyte + n * 128, (unsigned)(m * 16 + 4 * r) * crow);
     } else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            for (int n = 0; n < MT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
     }
 
-    double2_t ra[4], rb[4];
+    double2_t ra[LQ], rb[LQ];
     const int nk = (kend - kstart) / BK;
 
+    // Two workgroups share a CU (one wave of each per SIMD) and start together, so they would reach their
+    // barriers -- and leave the matrix pipe idle -- at the same moments.  The workgroup whose waves sit in the
+    // odd hardware wave slot starts a fraction of a stage later (a stage is ~4000 cycles of MFMA per wave).
+    if (BT == 128 && a.stagger) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (tid == 0) smem[0] = (double)(hwid & 1u);
+        __syncthreads();
+        const bool late = smem[0] != 0.0;
+        __syncthreads();
+        if (late) {
+            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles each
+        }
+    }
+
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < LQ; ++q) {
         ra[q] = *(const double2_t *)(ap + q * a32);
         rb[q] = *(const double2_t *)(bp + q * b32);
     }
     {
-        double *As = smem, *Bs = smem + GP_TILE * LSTR;
+        double *As = smem, *Bs = smem + BT * LSTR;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < LQ; ++q) {
             *(double2_t *)(As + soff + q * 32 * LSTR) = ra[q];
             *(double2_t *)(Bs + soff + q * 32 * LSTR) = rb[q];
         }
     }
     __syncthreads();
 
-    const int aoff = (wm * 64 + li) * LSTR + lg * 4;
-    const int boff = GP_TILE * LSTR + (wn * 64 + li) * LSTR + lg * 4;
+    const int aoff = (wm * WT + li) * LSTR + lg * 4;
+    const int boff = BT * LSTR + (wn * WT + li) * LSTR + lg * 4;
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -176,34 +208,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
             ap += BK;
             bp += BK;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < LQ; ++q) {
                 ra[q] = *(const double2_t *)(ap + q * a32);
                 rb[q] = *(const double2_t *)(bp + q * b32);
             }
         }
-        const double *as = smem + buf * (2 * GP_TILE * LSTR) + aoff;
-        const double *bs = smem + buf * (2 * GP_TILE * LSTR) + boff;
+        const double *as = smem + buf * (2 * BT * LSTR) + aoff;
+        const double *bs = smem + buf * (2 * BT * LSTR) + boff;
         // Lane group lg owns k = 4lg..4lg+3 of the stage; MFMA step (h,e) contracts k = 4g + 2h + e
         // over the four lane groups g, so two ds_read_b128 per operand row-tile feed four MFMA steps.
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            double2_t af[4], bf[4];
+            double2_t af[MT], bf[MT];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR + h * 2);
+            for (int m = 0; m < MT; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR + h * 2);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + h * 2);
+            for (int n = 0; n < MT; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + h * 2);
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
+                    for (int n = 0; n < MT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m][e], bf[n][e], acc[m][n], 0, 0, MODE == 1 ? 1 : 0);
         }
         if (more) {
-            double *As = smem + (buf ^ 1) * (2 * GP_TILE * LSTR), *Bs = As + GP_TILE * LSTR;
+            double *As = smem + (buf ^ 1) * (2 * BT * LSTR), *Bs = As + BT * LSTR;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < LQ; ++q) {
                 *(double2_t *)(As + soff + q * 32 * LSTR) = ra[q];
                 *(double2_t *)(Bs + soff + q * 32 * LSTR) = rb[q];
             }
@@ -212,9 +244,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     }
 
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < MT; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 buf_store_f64(crs, cbyte + n * 128, (unsigned)(m * 16 + 4 * r) * crow, acc[m][n][r]);
@@ -231,11 +263,20 @@ void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *
     a.k_tri = o.k_tri; a.k_end_tri = o.k_end_tri; a.b_sub = o.b_sub;
     a.sC = o.sC; a.sA = o.sA; a.sB = o.sB;
     a.tile_list = o.tile_list;
-    dim3 grid((unsigned)n, (unsigned)o.batch);
-    if (mode == 0)
-        hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, s, a);
+    a.stagger = o.stagger;
+    if (o.small) {
+        dim3 grid((unsigned)(4 * n), (unsigned)o.batch);
+        if (mode == 0)
+            hipLaunchKernelGGL((gemm_nt_kernel<0, 64>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nt_kernel<1, 64>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((unsigned)n, (unsigned)o.batch);
+        if (mode == 0)
+            hipLaunchKernelGGL((gemm_nt_kernel<0, 128>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nt_kernel<1, 128>), grid, dim3(256), 0, s, a);
+    }
 }
 
 std::vector<short> build_tile_list(const TileSet &ts, int S) {

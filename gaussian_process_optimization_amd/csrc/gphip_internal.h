@@ -43,6 +43,9 @@ struct GemmOpt {
     int batch = 1;      // blockIdx.y instances with pointer strides sC, sA, sB (elements)
     long sC = 0, sA = 0, sB = 0;
     const short *tile_list = nullptr;  // device pointer, 2 shorts per tile, tileset_count(ts) tiles
+    int stagger = 0;                   // odd-wave-slot workgroups start stagger * 1024 cycles late
+    int small = 0;                     // 64x64 workgroup tiles (4 workgroups per 128-tile): latency-bound launches
+    int inplace = 0;                   // C aliases A (tile-local product): the 128-tile must stay in one workgroup
 };
 // Host-side construction of an L2-friendly order: the tile set is cut into S x S super-tiles; the
 // list is dealt so that each XCD's contiguous run (see the remap in gemm.hip) walks whole super-tiles.

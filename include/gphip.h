@@ -99,6 +99,13 @@ int gp_set_candidates(gp_t *gp, const double *Xs, int64_t M);
  *   mean[M,P] = K(Xs,X) alpha;  var[M] = variance - sum_rows (L^-1 K(X,Xs))^2 (+ noise).  No clipping. */
 int gp_predict(gp_t *gp, int include_noise, double *mean, double *var);
 
+/* gp_fit + gp_predict on the resident candidates as ONE pipelined pass: the candidate solve of panel J starts
+ * as soon as panel J of L is final and fills the CUs that the factorisation's latency chain leaves idle.
+ * Same results as the two calls in sequence (BO.suggest_next_locations always runs them back to back:
+ * GPyOpt/GPyOpt/core/bo.py:236-254 then acquisitions/base.py:33-39). */
+int gp_fit_predict(gp_t *gp, int maxtries, int include_noise, double *lml, double *logdet, double *jitter_used,
+                   double *mean, double *var);
+
 /* full_cov = True branch (posterior.py:280-284): cov[M,M] = K(Xs) - tmp^T tmp (+ noise I). */
 int gp_predict_full_cov(gp_t *gp, int include_noise, double *mean, double *cov);
 
@@ -156,7 +163,8 @@ int gp_gemm_stats(gp_t *gp, int64_t *launches, double *ms, double *flops);
 int gp_gemm_trace(gp_t *gp, int cap, int64_t *tiles, int *K, double *ms);
 int gp_synchronize(gp_t *gp);
 /* tunables: "panel_tiles" (outer panel width in 128-tiles), "lookahead" (0/1),
- * "reserve_cus" (CUs kept free of the trailing update for the look-ahead chain), "mc_max" */
+ * "mc_max", "supertile".  The number of CUs kept free of the trailing update for the look-ahead chain is
+ * fixed per process (environment GPHIP_RESERVE_CUS, default 8). */
 int gp_set_option(gp_t *gp, const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -244,3 +244,39 @@ def test_state_errors(h):
     with pytest.raises(ValueError):
         hd.set_data(np.zeros((3, 65)), np.zeros((3, 1)))
     hd.close()
+
+
+@pytest.mark.parametrize("N,M,pt", [(1500, 700, 2), (2048, 300, 4), (1100, 129, 3), (600, 50, 8)])
+def test_fit_predict_pipelined_equals_separate_calls(h, N, M, pt):
+    """gp_fit_predict pipelines the candidate solve behind the factorisation; same arithmetic, same results."""
+    X, Y, Xs = O.synthetic_problem(N, 5, M, seed=N)
+    h.set_option("panel_tiles", pt)
+    h.set_data(X, Y)
+    h.set_params(1, 0, 1.2, [0.7], 1e-2)
+    h.set_candidates(Xs)
+    f0 = h.fit()
+    m0, v0 = h.predict(True)
+    a0 = h.alpha()
+    f1, m1, v1 = h.fit_predict(True)
+    assert f1 == f0
+    assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+    assert np.array_equal(a0, h.alpha())
+    # follow-up calls see a fitted, predicted state
+    e0 = h.acq(_lib.GP_ACQ_LCB, 2.0, 0.0)
+    h.fit(); h.predict(True)
+    assert np.array_equal(e0, h.acq(_lib.GP_ACQ_LCB, 2.0, 0.0))
+    gp = O.OracleGP(X, Y, O.Matern52(5, 1.2, 0.7), 1e-2)
+    mo, vo = gp.predict(Xs)
+    assert relmax(m1, mo) < 1e-6 and np.max(np.abs(v1 - vo) / vo) < 1e-6
+    h.set_option("panel_tiles", 8)
+
+
+def test_fit_predict_jitter_and_failure(golden, h):
+    h.set_data(golden["jit3/X"], golden["jit3/Y"])
+    h.set_params(_lib.GP_KERNEL_RBF, 0, 1.0, [0.5], float(golden["jit3/noise"]))
+    h.set_candidates(golden["jit3/X"][:10])
+    (lml, logdet, jit), m, v = h.fit_predict(True)
+    assert jit == pytest.approx(float(golden["jit3/jitter"]), rel=1e-12)
+    h.set_params(_lib.GP_KERNEL_RBF, 0, 1.0, [0.5], float(golden["jitfail/noise"]))
+    with pytest.raises(np.linalg.LinAlgError):
+        h.fit_predict(True)

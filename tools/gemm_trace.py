@@ -25,9 +25,11 @@ def run(N=16384, D=8, M=10000, panel=4):
             if big.any(): print("       launches with >=2048 tiles: %d, %.2f ms, %.2f TF" % (big.sum(), m[big].sum(), f[big].sum()/m[big].sum()/1e9))
             small = t < 512
             if small.any(): print("       launches with <512 tiles: %d, %.2f ms, %.2f TF, avg %.1f us" % (small.sum(), m[small].sum(), f[small].sum()/m[small].sum()/1e9, 1e3*m[small].mean()))
+        if what == "predict":
+            for t_, k_, m_ in zip(tiles, K, ms):
+                print("      tiles %6d K %6d  %8.3f ms  %6.2f TF" % (t_, k_, m_, 2.0*128*128*abs(k_)*t_*(0.5 if k_ < 0 else 1.0)/m_/1e9))
         h.profile(False)
     h.close()
 
 if __name__ == "__main__":
-    for p in (4, 8):
-        run(panel=p)
+    run(panel=8)

@@ -31,15 +31,20 @@ int main() {
             cus.insert((x << 16) | (se << 8) | (sh << 4) | cu); xccs.insert(x);
         }
         printf("%s: distinct CUs used %zu, XCCs %zu\n", name, cus.size(), xccs.size());
+        int per[8] = {0};
+        for (unsigned c : cus) per[c >> 16]++;
+        printf("   CUs per XCC:"); for (int x = 0; x < 8; ++x) printf(" %d", per[x]); printf("\n");
         return 0;
     };
     hipStream_t s0; CHK(hipStreamCreate(&s0));
     if (run(s0, "unmasked")) return 1;
-    for (int variant = 0; variant < 3; ++variant) {
+    for (int variant = 0; variant < 5; ++variant) {
         std::vector<uint32_t> mask(8, 0xffffffffu);
         if (variant == 0) mask[0] = 0xffff0000u;            // drop CUs 0..15
         if (variant == 1) for (int w = 0; w < 8; ++w) mask[w] = 0xfffffffcu;  // drop 2 bits per word
         if (variant == 2) { for (int w = 0; w < 8; ++w) mask[w] = 0; mask[0] = 0xffffu; }  // only CUs 0..15
+        if (variant == 3) mask[0] = 0xffffff00u;  // drop bits 0..7
+        if (variant == 4) { for (int w = 0; w < 8; ++w) mask[w] = 0; mask[0] = 0xffu; }  // only bits 0..7
         hipStream_t sm;
         hipError_t e = hipExtStreamCreateWithCUMask(&sm, 8, mask.data());
         if (e != hipSuccess) { printf("variant %d: create failed: %s\n", variant, hipGetErrorString(e)); continue; }

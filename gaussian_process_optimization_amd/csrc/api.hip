@@ -117,6 +117,7 @@ struct gp_ctx {
     std::map<std::array<int, 5>, short *> tile_lists;  // cached L2-friendly tile orders (device)
     int supertile = 0;
     int small_below = 1400;  // launches with fewer 128-tiles than this use 64x64 workgroup tiles
+    int waves8 = 1;
     int stagger = 3;  // see gemm.hip: odd-slot workgroups start 3 * 1024 cycles late (+1.5 % measured)
     int pipe_start_pct = 0;   // gp_fit_predict: candidate stages start once this share of the panels is factored
     std::vector<int> gemm_K;
@@ -238,6 +239,7 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
     }
     GemmOpt oo = o;
     if (n >= 1024 && !oo.stagger) oo.stagger = g->stagger;
+    if (n >= 1024 && g->waves8) oo.waves8 = 1;  // 4 waves/SIMD: +2 % on the long launches (measured)
     // short launches (the factorisation's latency chain, the uneven triangular-K products) run as 64x64 work units
     if (g->small_below > 0 && n < g->small_below && !oo.inplace) oo.small = 1;
     if (g->supertile > 1 && !o.tile_list && !o.k_end_tri && o.batch == 1 && tileset_count(ts) >= 2048) {
@@ -376,6 +378,8 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->pipe_start_pct = (int)value;
     } else if (!strcmp(name, "small_below")) {
         g->small_below = (int)value;
+    } else if (!strcmp(name, "waves8")) {
+        g->waves8 = value ? 1 : 0;
     } else if (!strcmp(name, "stagger")) {
         g->stagger = (int)value;
     } else if (!strcmp(name, "supertile")) {

@@ -92,11 +92,15 @@ __device__ __forceinline__ void tile_from_linear(long t, const GemmArgs &a, int 
 // 2x2 accumulators per wave, a quarter of the work per workgroup and up to 4 workgroups/CU -- used for the
 // short launches of the factorisation's latency chain and the uneven triangular-K products).  With BT = 64
 // every 128x128 tile of the tile set is computed by four workgroups.
-template <int MODE, int BT>
-__global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_nt_kernel(GemmArgs a) {
-    constexpr int MT = BT / 32;            // 16x16 MFMA tiles per wave along m and n
-    constexpr int WT = BT / 2;             // wave tile edge
-    constexpr int LQ = BT / 32;            // 16-byte staging loads per thread and operand
+template <int MODE, int BT, int NWN>
+__global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kernel(GemmArgs a) {
+    constexpr int NTH = 128 * NWN;         // threads: 2 x NWN waves
+    constexpr int MT = BT / 32;            // 16x16 MFMA tiles per wave along m
+    constexpr int NT = BT / NWN / 16;      // ... and along n
+    constexpr int WT = BT / 2;             // wave tile rows
+    constexpr int WTN = BT / NWN;          // wave tile columns
+    constexpr int LQ = BT * 8 / NTH;       // 16-byte staging loads per thread and operand
+    constexpr int LR = NTH / 8;            // rows covered by one staging load of the workgroup
     __shared__ __attribute__((aligned(16))) double smem[2 * 2 * BT * LSTR];  // [buf][A|B][BT][18]
 
     // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_nt_kernel(GemmA
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: C addressing stays scalar
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int li = lane & 15, lg = lane >> 4;
 
     const long z = blockIdx.y;
@@ -135,26 +139,26 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_nt_kernel(GemmA
     const double *Ag = a.A + z * a.sA + ((long)ti * GP_TILE + sr) * a.lda + kstart;
     const double *Bg = a.B + z * a.sB + ((long)(tc - a.b_sub) * a.b_mul * GP_TILE + sc) * a.ldb + kstart;
 
-    // staging map: BT rows x 8 chunks(16 B); thread handles rows (tid>>3) + 32q, chunk tid&7
+    // staging map: BT rows x 8 chunks(16 B); thread handles rows (tid>>3) + LR*q, chunk tid&7
     const int srow = tid >> 3, sch = (tid & 7) * 2;
     const double *ap = Ag + (long)srow * a.lda + sch;
     const double *bp = Bg + (long)srow * a.ldb + sch;
-    const long a32 = 32 * a.lda, b32 = 32 * a.ldb;
+    const long a32 = (long)LR * a.lda, b32 = (long)LR * a.ldb;
     const int soff = srow * LSTR + sch;
 
     // accumulator element r of tile (m,n) is C[row = lg + 4r][col = li] of that 16x16 tile
-    double *Cw = a.C + z * a.sC + ((long)ti * GP_TILE + sr + wm * WT) * a.ldc + (long)tc * GP_TILE + sc + wn * WT;  // uniform
+    double *Cw = a.C + z * a.sC + ((long)ti * GP_TILE + sr + wm * WT) * a.ldc + (long)tc * GP_TILE + sc + wn * WTN;  // uniform
     const unsigned cbyte = (unsigned)(lg * (int)a.ldc + li) * 8u;  // lane part of the address, bytes
     const unsigned crow = (unsigned)a.ldc * 8u;                    // row stride, bytes (wave tile spans <= 64 rows: < 2^31)
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(Cw, 0, 0x7fffffff, 0x00020000);
-    double4_t acc[MT][MT];
+    double4_t acc[MT][NT];
     if (MODE == 1) {
         // C -= A B^T: the old C rides in as the MFMA C operand (A negated by the f64 MFMA neg modifier), so
         // its HBM read overlaps the first operand-tile loads and the epilogue is stores only.
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < MT; ++n)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     acc[m][n][r] = buf_load_f64(crs, cbyte + n * 128, (unsigned)(m * 16 + 4 * r) * crow);
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_nt_kernel(GemmA
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < MT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
     }
 
     double2_t ra[LQ], rb[LQ];
@@ -192,14 +196,14 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_nt_kernel(GemmA
         double *As = smem, *Bs = smem + BT * LSTR;
 #pragma unroll
         for (int q = 0; q < LQ; ++q) {
-            *(double2_t *)(As + soff + q * 32 * LSTR) = ra[q];
-            *(double2_t *)(Bs + soff + q * 32 * LSTR) = rb[q];
+            *(double2_t *)(As + soff + q * LR * LSTR) = ra[q];
+            *(double2_t *)(Bs + soff + q * LR * LSTR) = rb[q];
         }
     }
     __syncthreads();
 
     const int aoff = (wm * WT + li) * LSTR + lg * 4;
-    const int boff = BT * LSTR + (wn * WT + li) * LSTR + lg * 4;
+    const int boff = BT * LSTR + (wn * WTN + li) * LSTR + lg * 4;
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -219,25 +223,25 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_nt_kernel(GemmA
         // over the four lane groups g, so two ds_read_b128 per operand row-tile feed four MFMA steps.
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            double2_t af[MT], bf[MT];
+            double2_t af[MT], bf[NT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR + h * 2);
 #pragma unroll
-            for (int n = 0; n < MT; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + h * 2);
+            for (int n = 0; n < NT; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + h * 2);
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < MT; ++n)
+                    for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m][e], bf[n][e], acc[m][n], 0, 0, MODE == 1 ? 1 : 0);
         }
         if (more) {
             double *As = smem + (buf ^ 1) * (2 * BT * LSTR), *Bs = As + BT * LSTR;
 #pragma unroll
             for (int q = 0; q < LQ; ++q) {
-                *(double2_t *)(As + soff + q * 32 * LSTR) = ra[q];
-                *(double2_t *)(Bs + soff + q * 32 * LSTR) = rb[q];
+                *(double2_t *)(As + soff + q * LR * LSTR) = ra[q];
+                *(double2_t *)(Bs + soff + q * LR * LSTR) = rb[q];
             }
         }
         __syncthreads();
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_nt_kernel(GemmA
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < MT; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 buf_store_f64(crs, cbyte + n * 128, (unsigned)(m * 16 + 4 * r) * crow, acc[m][n][r]);
@@ -267,15 +271,21 @@ void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *
     if (o.small) {
         dim3 grid((unsigned)(4 * n), (unsigned)o.batch);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_nt_kernel<0, 64>), grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((gemm_nt_kernel<0, 64, 2>), grid, dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, 64>), grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((gemm_nt_kernel<1, 64, 2>), grid, dim3(256), 0, s, a);
+    } else if (o.waves8) {
+        dim3 grid((unsigned)n, (unsigned)o.batch);
+        if (mode == 0)
+            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 4>), grid, dim3(512), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 4>), grid, dim3(512), 0, s, a);
     } else {
         dim3 grid((unsigned)n, (unsigned)o.batch);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_nt_kernel<0, 128>), grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 2>), grid, dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, 128>), grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 2>), grid, dim3(256), 0, s, a);
     }
 }
 

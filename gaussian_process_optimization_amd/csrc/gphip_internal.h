@@ -45,6 +45,7 @@ struct GemmOpt {
     const short *tile_list = nullptr;  // device pointer, 2 shorts per tile, tileset_count(ts) tiles
     int stagger = 0;                   // odd-wave-slot workgroups start stagger * 1024 cycles late
     int small = 0;                     // 64x64 workgroup tiles (4 workgroups per 128-tile): latency-bound launches
+    int waves8 = 0;                    // 128x128 tile on 8 waves (64x32 per wave, 4 waves/SIMD) instead of 4
     int inplace = 0;                   // C aliases A (tile-local product): the 128-tile must stay in one workgroup
 };
 // Host-side construction of an L2-friendly order: the tile set is cut into S x S super-tiles; the

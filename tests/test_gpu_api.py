@@ -174,3 +174,38 @@ def test_bayesian_optimization_loop_improves():
     i, v = bo.acquisition.argbest(table, -1)
     assert i == int(np.argmin(vals))
     bo.model.model.close()
+
+
+def test_rccl_comm_single_rank_and_sharded_wrapper():
+    """The RCCL entry points with a one-rank communicator (what a 1-GPU box can exercise): unique id, init,
+    all-gather of the (value, index) pair, broadcast of the fit, and the ShardedCandidates wrapper on top."""
+    from gaussian_process_optimization_amd import _lib
+    from gaussian_process_optimization_amd.sharded import RcclCollective, ShardedCandidates
+    X, Y, Xs = O.synthetic_problem(300, 3, 1000, seed=2)
+    h = _lib.Handle(0)
+    h.set_data(X, Y)
+    h.set_params(_lib.GP_KERNEL_MATERN52, 0, 1.0, [0.5], 1e-2)
+    h.fit()
+    uid = h.comm_unique_id()
+    assert len(uid) == 128
+    h.comm_init(uid, 0, 1)
+    vals, idxs = h.comm_allgather_best(-1.25, 77, 1)
+    assert vals.tolist() == [-1.25] and idxs.tolist() == [77]
+    lml0 = h.fit()[0]
+    h.comm_bcast_fit(0)           # root == self: state must survive unchanged
+    h.set_candidates(Xs)
+    m1, v1 = h.predict(True)
+    gp = O.OracleGP(X, Y, O.Matern52(3, 1.0, 0.5), 1e-2)
+    m0, v0 = gp.predict(Xs)
+    np.testing.assert_allclose(m1, m0, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(v1, v0, rtol=1e-6)
+
+    def score_local(Xb, sense):
+        h.set_candidates(Xb)
+        return h.acq_argbest(_lib.GP_ACQ_LCB, 2.0, 0.0, sense)
+    sc = ShardedCandidates(0, 1, RcclCollective(h, 1))
+    gi, gv = sc.argbest(Xs, score_local, -1)
+    a = h.acq(_lib.GP_ACQ_LCB, 2.0, 0.0)[:, 0]
+    assert gi == int(np.argmin(a)) and gv == a[gi]
+    h.lib.gp_comm_destroy(h.h)
+    h.close()

@@ -15,21 +15,21 @@ int main() {
     for (int r = 0; r < 8; ++r) CHK(hipMemcpy(A + (size_t)r * N * 2048, hostA.data(), hostA.size() * 8, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     const int nt = 128;
-    for (int stg : {0, 1, 2, 3, 4, 6}) for (int reserve : {0}) {
+    for (int w8 : {0, 1, 0, 1}) for (int stg : {0, 3}) for (int reserve : {0}) {
         hipStream_t s;
         std::vector<uint32_t> mask(8, 0xffffffffu);
         for (int i = 0; i < reserve; ++i) mask[i / 32] &= ~(1u << (i % 32));
         if (reserve) CHK(hipExtStreamCreateWithCUMask(&s, 8, mask.data())); else CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         TileSet ts{0, 79, 0, nt, 0};
         long ntile = tileset_count(ts);
-        GemmOpt o; o.stagger = stg;
+        GemmOpt o; o.stagger = stg; o.waves8 = w8;
         for (int w = 0; w < 3; ++w) launch_gemm_nt(s, 1, C, lda, A, lda, A + 4096, lda, 1, 1024, ts, o);
         CHK(hipStreamSynchronize(s));
         CHK(hipEventRecord(e0, s));
         for (int r = 0; r < 3; ++r) launch_gemm_nt(s, 1, C, lda, A, lda, A + 4096, lda, 1, 1024, ts, o);
         CHK(hipEventRecord(e1, s)); CHK(hipEventSynchronize(e1));
         float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
-        printf("stagger %d reserve %2d CUs: %8.3f ms  %6.2f TFLOP/s (x%.3f of CUs)\n", stg, reserve, ms, 2.0 * 128 * 128 * 1024 * ntile / ms / 1e9, (256.0 - reserve) / 256.0);
+        printf("waves8 %d stagger %d reserve %2d CUs: %8.3f ms  %6.2f TFLOP/s (x%.3f of CUs)\n", w8, stg, reserve, ms, 2.0 * 128 * 128 * 1024 * ntile / ms / 1e9, (256.0 - reserve) / 256.0);
     }
     return 0;
 }

@@ -19,7 +19,8 @@ from . import kern
 from .gp_regression import GPRegression, Gaussian, Standardize
 from .gpmodel import GPModel, BOModel
 from . import acquisitions
-from .acquisitions import AcquisitionEI, AcquisitionLCB, AcquisitionMPI, AcquisitionBase
+from .acquisitions import (AcquisitionEI, AcquisitionLCB, AcquisitionMPI, AcquisitionBase, AcquisitionLP,
+                           LocalPenalization, estimate_L)
 from .bayesian_optimization import BayesianOptimization, Design_space, AcquisitionOptimizer
 from .sharded import ShardedCandidates, merge_best
 
@@ -29,5 +30,6 @@ methods = _types.SimpleNamespace(BayesianOptimization=BayesianOptimization)
 likelihoods = _types.SimpleNamespace(Gaussian=Gaussian)
 
 __all__ = ["kern", "models", "methods", "likelihoods", "acquisitions", "GPRegression", "GPModel", "BOModel",
-           "AcquisitionEI", "AcquisitionLCB", "AcquisitionMPI", "AcquisitionBase", "BayesianOptimization",
+           "AcquisitionEI", "AcquisitionLCB", "AcquisitionMPI", "AcquisitionBase", "AcquisitionLP",
+           "LocalPenalization", "estimate_L", "BayesianOptimization",
            "Design_space", "AcquisitionOptimizer", "ShardedCandidates", "merge_best", "Standardize"]

@@ -50,6 +50,11 @@ SIGNATURES = [
                                       ctypes.c_double, ctypes.c_int, c_int64_p, c_double_p]),
     ("gp_acq_grad", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_double, c_double_p, c_double_p]),
+    ("gp_acq_lp", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                 ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
+    ("gp_acq_lp_argbest", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                         ctypes.c_double, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, c_double_p,
+                                         ctypes.c_int, c_int64_p, ctypes.c_int, c_int64_p, c_double_p]),
     ("gp_comm_unique_id", ctypes.c_int, [ctypes.c_char_p]),
     ("gp_comm_init", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     ("gp_comm_destroy", ctypes.c_int, [_vp]),
@@ -250,6 +255,32 @@ class Handle(object):
         check(self.lib, self.lib.gp_acq_argbest(self.h, int(type_), float(par), float(fmin), float(y_mean),
                                                 float(y_std), int(sense), ctypes.byref(idx), ctypes.byref(val)),
               "gp_acq_argbest")
+        return idx.value, val.value
+
+    def _lp_args(self, Xb, r_x0, s_x0):
+        if Xb is None:
+            return None, 0, None, None, None
+        Xb = as_f64(np.atleast_2d(Xb), 2)
+        r = as_f64(np.atleast_1d(r_x0), 1)
+        s = as_f64(np.atleast_1d(s_x0), 1)
+        return (Xb, r, s), Xb.shape[0], dptr(Xb), dptr(r), dptr(s)
+
+    def acq_lp(self, type_, par, fmin, transform, Xb=None, r_x0=None, s_x0=None, y_mean=0.0, y_std=1.0):
+        keep, nb, pX, pr, ps = self._lp_args(Xb, r_x0, s_x0)
+        out = np.empty(self.M)
+        check(self.lib, self.lib.gp_acq_lp(self.h, int(type_), float(par), float(fmin), float(y_mean), float(y_std),
+                                           int(transform), pX, nb, pr, ps, dptr(out)), "gp_acq_lp")
+        return out
+
+    def acq_lp_argbest(self, type_, par, fmin, transform, sense, Xb=None, r_x0=None, s_x0=None, exclude=(),
+                       y_mean=0.0, y_std=1.0):
+        keep, nb, pX, pr, ps = self._lp_args(Xb, r_x0, s_x0)
+        ex = np.asarray(list(exclude), dtype=np.int64)
+        idx, val = ctypes.c_int64(), ctypes.c_double()
+        check(self.lib, self.lib.gp_acq_lp_argbest(self.h, int(type_), float(par), float(fmin), float(y_mean),
+                                                   float(y_std), int(transform), pX, nb, pr, ps, int(sense),
+                                                   ex.ctypes.data_as(c_int64_p), int(ex.size), ctypes.byref(idx),
+                                                   ctypes.byref(val)), "gp_acq_lp_argbest")
         return idx.value, val.value
 
     def phases(self):

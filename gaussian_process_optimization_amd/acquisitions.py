@@ -211,3 +211,199 @@ class AcquisitionMPI(AcquisitionBase):
         m, s, dmdx, dsdx = self.model.predict_withGradients(x)
         phi, Phi, u = get_quantiles(self.jitter, fmin, m, s)
         return Phi, -(phi / s) * (dmdx + dsdx * u)
+
+
+class AcquisitionLP(AcquisitionBase):
+    """Local-penalisation acquisition for batch design, GPyOpt/GPyOpt/acquisitions/LP.py:10-140.
+
+    Always in log space: ``-T(acq(x)) - sum_k log Phi((|x - x0_k| - r_k) / s_k)``.  On the HIP path the whole
+    candidate table is scored on the device (gp_acq_lp: the base EI / LCB / MPI kernel plus the hammer-function
+    epilogue); the reference's NumPy formulas remain as the path for foreign models and for gradients.
+    """
+    analytical_gradient_prediction = True
+
+    def __init__(self, model, space=None, optimizer=None, acquisition=None, transform='none'):
+        super(AcquisitionLP, self).__init__(model, space, optimizer)
+        self.acq = acquisition
+        self.transform = transform.lower()
+        if isinstance(acquisition, AcquisitionLCB) and self.transform == 'none':
+            self.transform = 'softplus'                      # LP.py:32-35
+        self.X_batch = None
+        self.r_x0 = None
+        self.s_x0 = None
+
+    def update_batches(self, X_batch, L, Min):
+        """LP.py:41-47."""
+        self.X_batch = X_batch
+        if X_batch is not None:
+            self.r_x0, self.s_x0 = self._hammer_function_precompute(X_batch, L, Min, self.model)
+
+    def _hammer_function_precompute(self, x0, L, Min, model):
+        """LP.py:49-62 (the reference feeds the model's *std* into ``pred`` and takes its square root again)."""
+        if x0 is None:
+            return None, None
+        if len(x0.shape) == 1:
+            x0 = x0[None, :]
+        m = model.predict(x0)[0]
+        pred = model.predict(x0)[1].copy()
+        pred[pred < 1e-16] = 1e-16
+        s = np.sqrt(pred)
+        r_x0 = (m - Min) / L
+        s_x0 = s / L
+        return r_x0.flatten(), s_x0.flatten()
+
+    def _hammer_function(self, x, x0, r_x0, s_x0):
+        """LP.py:64-68."""
+        from scipy.stats import norm
+        return norm.logcdf((np.sqrt((np.square(np.atleast_2d(x)[:, None, :] - np.atleast_2d(x0)[None, :, :])).sum(-1))
+                            - r_x0) / s_x0)
+
+    def _penalized_acquisition(self, x, model, X_batch, r_x0, s_x0):
+        """LP.py:70-89 (host formulas)."""
+        fval = -self.acq.acquisition_function(x)[:, 0]
+        if self.transform == 'softplus':
+            fval_org = fval.copy()
+            fval[fval_org >= 40.] = np.log(fval_org[fval_org >= 40.])
+            fval[fval_org < 40.] = np.log(np.log1p(np.exp(fval_org[fval_org < 40.])))
+        elif self.transform == 'none':
+            fval = np.log(fval + 1e-50)
+        fval = -fval
+        if X_batch is not None:
+            h_vals = self._hammer_function(x, X_batch, r_x0, s_x0)
+            fval += -h_vals.sum(axis=-1)
+        return fval
+
+    def _d_hammer_function(self, x, X_batch, r_x0, s_x0):
+        """LP.py:91-103."""
+        from scipy.stats import norm
+        dx = np.atleast_2d(x)[:, None, :] - np.atleast_2d(X_batch)[None, :, :]
+        nm = np.sqrt((np.square(dx)).sum(-1))
+        z = (nm - r_x0) / s_x0
+        h_func = norm.cdf(z)
+        d = 1. / (s_x0 * np.sqrt(2 * np.pi) * h_func) * np.exp(-np.square(z) / 2) / nm
+        d[h_func < 1e-50] = 0.
+        d = d[:, :, None]
+        return d.sum(axis=1)
+
+    # -- device fast path -----------------------------------------------------------------
+    def _lp_device_ok(self):
+        return (self.acq is not None and self.acq.model is self.model and self.acq._device_ok()
+                and self.transform in ('none', 'softplus'))
+
+    def _lp_device_args(self, x):
+        gp, fmin, y_mean, y_std = self.acq._device_stage(x)
+        tr = 1 if self.transform == 'softplus' else 0
+        return gp, (self.acq._acq_id, self.acq._par(), fmin, tr), dict(Xb=self.X_batch, r_x0=self.r_x0, s_x0=self.s_x0,
+                                                                      y_mean=y_mean, y_std=y_std)
+
+    def acquisition_function(self, x):
+        """LP.py:105-110.  Returns a 1-D array like the reference."""
+        if self._lp_device_ok():
+            gp, a, kw = self._lp_device_args(x)
+            return gp._h.acq_lp(*a, **kw)
+        return self._penalized_acquisition(x, self.model, self.X_batch, self.r_x0, self.s_x0)
+
+    def argbest(self, x, sense=+1, exclude=()):
+        """Arg-best of ``acquisition_function(x)`` with already-chosen rows masked (run.py:1241,1249-1252)."""
+        if self._lp_device_ok():
+            gp, a, kw = self._lp_device_args(x)
+            return gp._h.acq_lp_argbest(a[0], a[1], a[2], a[3], sense, exclude=exclude, **kw)
+        v = np.ma.array(self.acquisition_function(x), mask=False)
+        for e in exclude:
+            v.mask[e] = True
+        i = int(np.argmax(v) if sense > 0 else np.argmin(v))
+        return i, float(v[i])
+
+    def d_acquisition_function(self, x):
+        """LP.py:112-133."""
+        x = np.atleast_2d(x)
+        if self.transform == 'softplus':
+            fval = -self.acq.acquisition_function(x)[:, 0]
+            scale = 1. / (np.log1p(np.exp(fval)) * (1. + np.exp(-fval)))
+        elif self.transform == 'none':
+            fval = -self.acq.acquisition_function(x)[:, 0]
+            scale = 1. / fval
+        else:
+            scale = 1.
+        # the reference multiplies a length-M vector with an [M, D] gradient, which only broadcasts for the
+        # single-row calls L-BFGS makes; a column keeps those values and also serves M > 1
+        scale = np.atleast_1d(scale)[:, None] if np.ndim(scale) else scale
+        _, grad_acq_x = self.acq.acquisition_function_withGradients(x)
+        if self.X_batch is None:
+            return scale * grad_acq_x
+        return scale * grad_acq_x - self._d_hammer_function(x, self.X_batch, self.r_x0, self.s_x0)
+
+    def acquisition_function_withGradients(self, x):
+        """LP.py:135-140."""
+        return self.acquisition_function(x), self.d_acquisition_function(x)
+
+
+def estimate_L(model, bounds, storehistory=True):
+    """Lipschitz constant of the posterior mean, GPyOpt/GPyOpt/core/evaluators/batch_local_penalization.py:52-70.
+
+    ``model`` is the GP (``GPModel.model``); its predictive gradients over the 500 + N sample points come from
+    one batched device call."""
+    from scipy import optimize as _sopt
+
+    def df(x, model, x0):
+        x = np.atleast_2d(x)
+        dmdx, _ = model.predictive_gradients(x)
+        res = np.sqrt((dmdx * dmdx).sum(1))
+        return -res
+
+    bounds = list(bounds)
+    lo = np.array([b[0] for b in bounds], dtype=float)
+    hi = np.array([b[1] for b in bounds], dtype=float)
+    samples = np.random.uniform(size=(500, len(bounds))) * (hi - lo) + lo     # samples_multidimensional_uniform
+    samples = np.vstack([samples, model.X])
+    pred_samples = df(samples, model, 0)
+    x0 = samples[np.argmin(pred_samples)]
+    res = _sopt.minimize(lambda x: float(df(x, model, x0).ravel()[0]), x0, method='L-BFGS-B', bounds=bounds,
+                         options={'maxiter': 200})
+    L = -float(res.fun)
+    if L < 1e-7:
+        L = 10  # flat model
+    return L
+
+
+class LocalPenalization(object):
+    """Batch evaluator of Gonzalez et al. 2016, core/evaluators/batch_local_penalization.py:7-49."""
+
+    def __init__(self, acquisition, batch_size):
+        self.acquisition = acquisition
+        self.batch_size = batch_size
+
+    def compute_batch(self, duplicate_manager=None, context_manager=None):
+        assert isinstance(self.acquisition, AcquisitionLP)
+        self.acquisition.update_batches(None, None, None)
+        X_batch = self.acquisition.optimize()[0]
+        k = 1
+        if self.batch_size > 1:
+            L = estimate_L(self.acquisition.model.model, self.acquisition.space.get_bounds())
+            Min = self.acquisition.model.model.Y.min()
+        while k < self.batch_size:
+            self.acquisition.update_batches(X_batch, L, Min)
+            new_sample = self.acquisition.optimize()[0]
+            X_batch = np.vstack((X_batch, new_sample))
+            k += 1
+        self.acquisition.update_batches(None, None, None)
+        return X_batch
+
+    def compute_batch_from_table(self, table, sense=+1):
+        """The candidate-table variant the thesis driver uses (run.py:1234-1258): pick ``batch_size`` rows of
+        ``table`` by repeated arg-best of the penalised acquisition, never the same row twice."""
+        acq = self.acquisition
+        acq.update_batches(None, None, None)
+        i, _ = acq.argbest(table, sense)
+        chosen = [i]
+        X_batch = table[i]
+        if self.batch_size > 1:
+            L = estimate_L(acq.model.model, acq.space.get_bounds())
+            Min = acq.model.model.Y.min()
+        while len(chosen) < self.batch_size:
+            acq.update_batches(np.atleast_2d(X_batch), L, Min)
+            i, _ = acq.argbest(table, sense, exclude=chosen)
+            chosen.append(i)
+            X_batch = np.vstack((X_batch, table[i]))
+        acq.update_batches(None, None, None)
+        return chosen

@@ -19,7 +19,7 @@ import numpy as np
 from scipy import optimize as _sopt
 
 from . import kern as _kern
-from .acquisitions import AcquisitionEI, AcquisitionLCB, AcquisitionMPI
+from .acquisitions import AcquisitionEI, AcquisitionLCB, AcquisitionMPI, AcquisitionLP, LocalPenalization
 from .gpmodel import GPModel
 
 
@@ -140,8 +140,12 @@ class BayesianOptimization(object):
                  maximize=False, de_duplication=False, model=None, acquisition=None, device=0, **kwargs):
         if model_type not in ('GP',) and model is None:
             raise NotImplementedError("model_type %r is outside the accelerated path" % model_type)
-        if evaluator_type != 'sequential' or batch_size != 1:
-            raise NotImplementedError("batch evaluators are listed under 'next' in SURVEY.md 8(f)")
+        if evaluator_type not in ('sequential', 'local_penalization'):
+            raise NotImplementedError("evaluator %r is outside the accelerated path" % evaluator_type)
+        if evaluator_type == 'sequential' and batch_size != 1:
+            raise NotImplementedError("the sequential evaluator proposes one point at a time")
+        self.evaluator_type = evaluator_type
+        self.batch_size = batch_size
         self.f = f
         self.maximize = maximize
         self.space = Design_space(domain, constraints)
@@ -173,6 +177,14 @@ class BayesianOptimization(object):
             self.acquisition = AcquisitionMPI(self.model, self.space, self.acquisition_optimizer, cost_withGradients, jitter)
         else:
             raise NotImplementedError("acquisition %r is outside the accelerated path" % acquisition_type)
+        # arguments_manager.py:17-38 (evaluator_creator): local penalisation wraps the acquisition (LP.py)
+        if evaluator_type == 'local_penalization':
+            if not isinstance(self.acquisition, AcquisitionLP):
+                self.acquisition = AcquisitionLP(self.model, self.space, self.acquisition_optimizer, self.acquisition,
+                                                 transform=kwargs.get('acquisition_transformation', 'none'))
+            self.evaluator = LocalPenalization(self.acquisition, batch_size)
+        else:
+            self.evaluator = None
         # initial data
         if X is None:
             X = self.space.samples_uniform(initial_design_numdata)
@@ -198,6 +210,8 @@ class BayesianOptimization(object):
 
     # -- core/bo.py:216-234 ----------------------------------------------------------------
     def _compute_next_evaluations(self, pending_zipped_X=None, ignored_zipped_X=None):
+        if self.evaluator is not None:
+            return self.evaluator.compute_batch()
         x, _ = self.acquisition.optimize()
         return x
 

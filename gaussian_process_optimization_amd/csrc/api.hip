@@ -95,6 +95,8 @@ struct gp_ctx {
     bool wi_valid = false;
     double *dT2 = nullptr;   // solved candidate rows S = K(Xs,X) L^-T (the running right-hand side stays in dT)
     long capT2 = 0;
+    double *dLp = nullptr;   // local-penalisation batch (centres, radii, scales)
+    long capLp = 0;
     double *dCov = nullptr;  // full covariance / beta scratch
     long capCov = 0;
     double *dInvP = nullptr, *dInvPw = nullptr;  // inverted diagonal panels L_JJ^-1 (+ build workspace)
@@ -337,7 +339,7 @@ int gp_create(gp_t **out, int device) {
     HIPCHK(hipMalloc((void **)&g->dInfo, sizeof(int) * 4));
     HIPCHK(hipMalloc((void **)&g->dScal, sizeof(double) * 512));
     HIPCHK(hipMalloc((void **)&g->dRedV, sizeof(double) * 512));
-    HIPCHK(hipMalloc((void **)&g->dRedI, sizeof(long long) * 512));
+    HIPCHK(hipMalloc((void **)&g->dRedI, sizeof(long long) * 1024));
     *out = g;
     return 0;
 }
@@ -348,7 +350,7 @@ int gp_destroy(gp_t *g) {
     hipDeviceSynchronize();
     if (g->comm) ncclCommDestroy(g->comm);
     double *ptrs[] = {g->dX, g->dY, g->dA, g->dInvL, g->dAlpha, g->dW, g->dMu, g->dScal, g->dRedV,
-                      g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi, g->dT2, g->dDm, g->dDv, g->dDacq, g->dCov, g->dInvP, g->dInvPw};
+                      g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi, g->dT2, g->dDm, g->dDv, g->dDacq, g->dCov, g->dInvP, g->dInvPw, g->dLp};
     for (double *p : ptrs)
         if (p) hipFree(p);
     if (g->dInfo) hipFree(g->dInfo);
@@ -1053,6 +1055,67 @@ int gp_acq_argbest(gp_t *g, int type, double par, double fmin, double y_mean, do
     HIPCHK(hipSetDevice(g->device));
     int rc;
     if ((rc = run_acq(g, type, par, fmin, y_mean, y_std))) return rc;
+    launch_argbest(g->s, g->dAcq, g->M, sense, g->dRedV + 256, g->dRedI + 256, g->dRedV, g->dRedI);
+    double v = 0.0;
+    long long i = 0;
+    HIPCHK(hipMemcpyAsync(&v, g->dRedV + 256, sizeof(double), hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipMemcpyAsync(&i, g->dRedI + 256, sizeof(long long), hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    *val = v;
+    *idx = (int64_t)i;
+    return 0;
+}
+
+// ---- local penalisation (batch acquisition of run.py:1238-1257; GPyOpt/GPyOpt/acquisitions/LP.py) -----------
+static int run_acq_lp(gp_ctx *g, int type, double par, double fmin, double y_mean, double y_std, int transform,
+                      const double *Xb, int nb, const double *r0, const double *s0) {
+    if (nb < 0 || nb > 256) return fail(GP_ERR_ARG, "batch size out of range (0..256)");
+    int rc;
+    if ((rc = run_acq(g, type, par, fmin, y_mean, y_std))) return rc;
+    // small batch arrays live behind the reduction scratch
+    int rcb;
+    if ((rcb = dev_realloc(&g->dLp, &g->capLp, (long)256 * (GP_MAX_D + 2)))) return rcb;
+    double *dXb = g->dLp, *dr = g->dLp + 256 * GP_MAX_D, *ds = dr + 256;
+    if (nb > 0) {
+        HIPCHK(hipMemcpyAsync(dXb, Xb, sizeof(double) * nb * g->D, hipMemcpyHostToDevice, g->s));
+        HIPCHK(hipMemcpyAsync(dr, r0, sizeof(double) * nb, hipMemcpyHostToDevice, g->s));
+        HIPCHK(hipMemcpyAsync(ds, s0, sizeof(double) * nb, hipMemcpyHostToDevice, g->s));
+    }
+    launch_lp(g->s, g->dAcq, g->dXs, g->M, g->D, dXb, nb, dr, ds, transform, g->dAcq);
+    return 0;
+}
+
+int gp_acq_lp(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, int transform,
+              const double *Xb, int nb, const double *r_x0, const double *s_x0, double *out) {
+    if (!g || !out || (nb > 0 && (!Xb || !r_x0 || !s_x0))) return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = run_acq_lp(g, type, par, fmin, y_mean, y_std, transform, Xb, nb, r_x0, s_x0))) return rc;
+    HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    return 0;
+}
+
+int gp_acq_lp_argbest(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, int transform,
+                      const double *Xb, int nb, const double *r_x0, const double *s_x0, int sense,
+                      const int64_t *exclude, int nex, int64_t *idx, double *val) {
+    if (!g || !idx || !val || (nb > 0 && (!Xb || !r_x0 || !s_x0)) || (nex > 0 && !exclude))
+        return fail(GP_ERR_ARG, "null argument");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    if (sense != 1 && sense != -1) return fail(GP_ERR_ARG, "sense must be +1 or -1");
+    if (nex < 0 || nex > 256) return fail(GP_ERR_ARG, "too many excluded rows (<= 256)");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = run_acq_lp(g, type, par, fmin, y_mean, y_std, transform, Xb, nb, r_x0, s_x0))) return rc;
+    if (nex > 0) {  // rows already taken never win (run.py:1249-1252 masks them)
+        for (int i = 0; i < nex; ++i)
+            if (exclude[i] < 0 || exclude[i] >= g->M) return fail(GP_ERR_ARG, "excluded row out of range");
+        HIPCHK(hipMemcpyAsync(g->dRedI + 300, exclude, sizeof(long long) * nex, hipMemcpyHostToDevice, g->s));
+        launch_mask(g->s, g->dAcq, g->dRedI + 300, nex, sense > 0 ? -INFINITY : INFINITY);
+    }
     launch_argbest(g->s, g->dAcq, g->M, sense, g->dRedV + 256, g->dRedI + 256, g->dRedV, g->dRedI);
     double v = 0.0;
     long long i = 0;

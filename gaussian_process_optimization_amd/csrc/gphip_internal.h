@@ -114,3 +114,6 @@ void launch_trace(hipStream_t s, const double *A, long lda, long N, double *out)
 // nb blocks of n x n (row-major, leading dimension n, stacked): identity / transpose (dst_b = src_b^T)
 void launch_set_identity_blocks(hipStream_t s, double *T, long n, int nb);
 void launch_transpose_blocks(hipStream_t s, double *dst, const double *src, long n, int nb);
+void launch_lp(hipStream_t s, const double *negacq, const double *Xs, long M, int D, const double *Xb, int nb,
+               const double *r0, const double *s0, int transform, double *out);
+void launch_mask(hipStream_t s, double *v, const long long *idx, int n, double fill);

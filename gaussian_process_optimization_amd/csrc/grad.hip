@@ -360,3 +360,59 @@ void launch_transpose_blocks(hipStream_t s, double *dst, const double *src, long
     dim3 grid((unsigned)(n / 32), (unsigned)(n / 32), (unsigned)nb);
     hipLaunchKernelGGL(transpose_blocks_kernel, grid, dim3(256), 0, s, dst, src, n);
 }
+
+// ---- local-penalisation epilogue (GPyOpt/GPyOpt/acquisitions/LP.py:40-110) -----------------------------
+// scipy.stats.norm.logcdf == cephes log_ndtr: log(ndtr(z)) for z > -20, the asymptotic series below it,
+// -ndtr(-z) above 6.
+__device__ __forceinline__ double log_ndtr(double z) {
+    if (z > 6.0) return -0.5 * erfc(z / 1.41421356237309504880168872420970);
+    if (z > -20.0) return log(0.5 * erfc(-z / 1.41421356237309504880168872420970));
+    const double log_lhs = -0.5 * z * z - log(-z) - 0.5 * log(2.0 * 3.14159265358979323846);
+    double last_total = 0.0, right_hand_side = 1.0, numerator = 1.0, denom_factor = 1.0;
+    const double denom_cons = 1.0 / (z * z);
+    long sign = 1, i = 0;
+    while (fabs(last_total - right_hand_side) > 2.220446049250313e-16) {
+        i += 1;
+        last_total = right_hand_side;
+        sign = -sign;
+        denom_factor *= denom_cons;
+        numerator *= (double)(2 * i - 1);
+        right_hand_side += (double)sign * numerator * denom_factor;
+        if (i > 200) break;
+    }
+    return log_lhs + log(right_hand_side);
+}
+// in: negacq[M] = -acq(x) (gp_acq output).  out[M] = -log-transformed acq - sum_k logcdf((|x - x0_k| - r_k)/s_k)
+// transform: 0 = none (log(acq + 1e-50)), 1 = softplus (LP.py:77-83)
+__global__ void lp_kernel(const double *negacq, const double *Xs, long M, int D, const double *Xb, int nb,
+                          const double *r0, const double *s0, int transform, double *out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    double f = -negacq[i];
+    if (transform == 1)
+        f = (f >= 40.0) ? log(f) : log(log1p(exp(f)));
+    else
+        f = log(f + 1e-50);
+    f = -f;
+    for (int k = 0; k < nb; ++k) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double df = Xs[i * D + d] - Xb[k * D + d];
+            d2 = fma(df, df, d2);
+        }
+        f -= log_ndtr((sqrt(d2) - r0[k]) / s0[k]);
+    }
+    out[i] = f;
+}
+void launch_lp(hipStream_t s, const double *negacq, const double *Xs, long M, int D, const double *Xb, int nb,
+               const double *r0, const double *s0, int transform, double *out) {
+    hipLaunchKernelGGL(lp_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, negacq, Xs, M, D, Xb, nb, r0, s0,
+                       transform, out);
+}
+__global__ void mask_kernel(double *v, const long long *idx, int n, double fill) {
+    const int i = threadIdx.x;
+    if (i < n) v[idx[i]] = fill;
+}
+void launch_mask(hipStream_t s, double *v, const long long *idx, int n, double fill) {
+    if (n > 0) hipLaunchKernelGGL(mask_kernel, dim3(1), dim3(256), 0, s, v, idx, n, fill);
+}

@@ -137,6 +137,19 @@ int gp_acq_argbest(gp_t *gp, int type, double par, double fmin, double y_mean, d
 int gp_acq_grad(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std,
                 double *out, double *dout);
 
+/* Local-penalisation batch acquisition on the resident candidates (the evaluator run.py:1219,1238-1257 uses):
+ * AcquisitionLP._penalized_acquisition (GPyOpt/GPyOpt/acquisitions/LP.py:70-89):
+ *   out = -T(acq(x)) - sum_k log Phi((|x - Xb_k| - r_x0[k]) / s_x0[k]),  T = log(. + 1e-50) (transform 0) or
+ *   log(softplus(.)) (transform 1); acq is the base EI / LCB / MPI value; r_x0, s_x0 from
+ *   _hammer_function_precompute (LP.py:49-62), computed by the host from gp_predict at the batch points.
+ * nb = 0 gives the un-penalised log acquisition.  out[M] as the reference returns it (to be minimised). */
+int gp_acq_lp(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std, int transform,
+              const double *Xb, int nb, const double *r_x0, const double *s_x0, double *out);
+/* arg-best of the same vector, skipping the rows listed in exclude (run.py:1249-1252). */
+int gp_acq_lp_argbest(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std, int transform,
+                      const double *Xb, int nb, const double *r_x0, const double *s_x0, int sense,
+                      const int64_t *exclude, int nex, int64_t *idx, double *val);
+
 /* ---- multi-GPU (one process per GPU; RCCL over xGMI) ---------------------
  * The candidate table shards across ranks; every rank holds a replica of the
  * fitted model.  uid is ncclUniqueId (128 bytes) produced on rank 0 and carried

@@ -617,3 +617,60 @@ def fit_predict_iteration(kern, X, Y, noise_var, Xs, as_gpy=False):
     var = (kern.Kdiag(Xs) - np.square(tmp).sum(0))[:, None]
     t["dtrtrs_var"] = time.perf_counter() - t0
     return float(lml), mu, var, t
+
+
+# ----------------------------------------------------------------------------
+# Local penalisation (GPyOpt/GPyOpt/acquisitions/LP.py)
+# ----------------------------------------------------------------------------
+def lp_hammer_precompute(model, x0, L, Min):
+    """AcquisitionLP._hammer_function_precompute, LP.py:49-62."""
+    if x0.ndim == 1:
+        x0 = x0[None, :]
+    m = model.predict(x0)[0]
+    pred = model.predict(x0)[1].copy()
+    pred[pred < 1e-16] = 1e-16
+    s = np.sqrt(pred)
+    return ((m - Min) / L).flatten(), (s / L).flatten()
+
+
+def lp_penalized_acquisition(neg_acq, x, X_batch, r_x0, s_x0, transform="none"):
+    """AcquisitionLP._penalized_acquisition, LP.py:70-89.  neg_acq = base acquisition_function(x) ([M,1], negated)."""
+    from scipy.stats import norm
+    fval = -neg_acq[:, 0].copy()
+    if transform == "softplus":
+        fval_org = fval.copy()
+        fval[fval_org >= 40.] = np.log(fval_org[fval_org >= 40.])
+        fval[fval_org < 40.] = np.log(np.log1p(np.exp(fval_org[fval_org < 40.])))
+    elif transform == "none":
+        fval = np.log(fval + 1e-50)
+    fval = -fval
+    if X_batch is not None:
+        h = norm.logcdf((np.sqrt((np.square(np.atleast_2d(x)[:, None, :] - np.atleast_2d(X_batch)[None, :, :])).sum(-1))
+                         - r_x0) / s_x0)
+        fval += -h.sum(axis=-1)
+    return fval
+
+
+def lp_d_acquisition(neg_acq, neg_dacq, x, X_batch, r_x0, s_x0, transform="none"):
+    """AcquisitionLP.d_acquisition_function, LP.py:112-133, with _d_hammer_function (LP.py:91-103) verbatim --
+    including its omission of the direction (x - x0) / |x - x0|: the reference sums a scalar per point over the
+    batch and broadcasts it over the input dimensions.  Restated as is (bug-compatible drop-in)."""
+    from scipy.stats import norm
+    x = np.atleast_2d(x)
+    fval = -neg_acq[:, 0]
+    if transform == "softplus":
+        scale = 1. / (np.log1p(np.exp(fval)) * (1. + np.exp(-fval)))
+    elif transform == "none":
+        scale = 1. / fval
+    else:
+        scale = np.ones_like(fval)
+    g = scale[:, None] * neg_dacq
+    if X_batch is None:
+        return g
+    dx = x[:, None, :] - np.atleast_2d(X_batch)[None, :, :]
+    nm = np.sqrt((np.square(dx)).sum(-1))
+    z = (nm - r_x0) / s_x0
+    h_func = norm.cdf(z)
+    d = 1. / (s_x0 * np.sqrt(2 * np.pi) * h_func) * np.exp(-np.square(z) / 2) / nm
+    d[h_func < 1e-50] = 0.
+    return g - d[:, :, None].sum(axis=1)

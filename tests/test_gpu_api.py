@@ -209,3 +209,83 @@ def test_rccl_comm_single_rank_and_sharded_wrapper():
     assert gi == int(np.argmin(a)) and gv == a[gi]
     h.lib.gp_comm_destroy(h.h)
     h.close()
+
+
+@pytest.mark.parametrize("base", ["EI", "LCB", "MPI"])
+def test_local_penalization_matches_reference_formulas(base):
+    """AcquisitionLP on the device (gp_acq_lp) vs the restated LP.py formulas on oracle predictions."""
+    X, Y, table = O.synthetic_problem(180, 3, 1500, seed=33)
+    gm = gpo.GPModel(kernel=gpo.kern.Matern52(3, 1.1, 0.5), noise_var=0.02, max_iters=0, verbose=False)
+    gm.updateModel(X, Y, None, None)
+    gp0, gm0 = _oracle_twin(X, Y, "Mat52", [0.5], 1.1, 0.02)
+    cls = {"EI": gpo.AcquisitionEI, "LCB": gpo.AcquisitionLCB, "MPI": gpo.AcquisitionMPI}[base]
+    fn0 = {"EI": lambda x: O.acq_EI(gm0, x, 0.01), "LCB": lambda x: O.acq_LCB(gm0, x, 2.0),
+           "MPI": lambda x: O.acq_MPI(gm0, x, 0.01)}[base]
+    space = gpo.Design_space([{'name': 'x', 'type': 'continuous', 'domain': (0, 1), 'dimensionality': 3}])
+    lp = gpo.AcquisitionLP(gm, space, None, cls(gm, space))
+    tr = "softplus" if base == "LCB" else "none"
+    assert lp.transform == tr
+    # un-penalised
+    v = lp.acquisition_function(table)
+    ref = O.lp_penalized_acquisition(-fn0(table), table, None, None, None, tr)
+    np.testing.assert_allclose(v, ref, rtol=1e-6, atol=1e-9)
+    # penalised with a 3-point batch; L and Min as compute_batch would supply them
+    Xb = table[[5, 200, 900]]
+    L, Min = 3.7, float(Y.min())
+    lp.update_batches(Xb, L, Min)
+    r0, s0 = O.lp_hammer_precompute(gm0, Xb, L, Min)
+    np.testing.assert_allclose(lp.r_x0, r0, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(lp.s_x0, s0, rtol=1e-6)
+    v = lp.acquisition_function(table)
+    ref = O.lp_penalized_acquisition(-fn0(table), table, Xb, r0, s0, tr)
+    np.testing.assert_allclose(v, ref, rtol=1e-6, atol=1e-8)
+    host = lp._penalized_acquisition(table, gm, Xb, lp.r_x0, lp.s_x0)      # reference formulas on device predictions
+    np.testing.assert_allclose(v, host, rtol=1e-9, atol=1e-9)
+    # arg-best with exclusion == masked argmax of the reference vector (run.py:1249-1252)
+    taken = [int(np.argmax(v)), 17]
+    i, val = lp.argbest(table, +1, exclude=taken)
+    mv = np.ma.array(v, mask=False); mv.mask[taken] = True
+    assert i == int(np.argmax(mv)) and val == v[i]
+    # gradients: the reference's own formula (LP.py:91-133), which drops the direction factor of the penaliser
+    # gradient -- kept bug-compatible, so compared with its restatement rather than with finite differences
+    xq = table[:4] * 0.8 + 0.1
+    f, df = lp.acquisition_function_withGradients(xq)
+    fng = {"EI": lambda x: O.acq_EI_withGradients(gm0, x, 0.01), "LCB": lambda x: O.acq_LCB_withGradients(gm0, x, 2.0),
+           "MPI": lambda x: O.acq_MPI_withGradients(gm0, x, 0.01)}[base]
+    a0, da0 = fng(xq)
+    ref_d = O.lp_d_acquisition(-a0, -da0, xq, Xb, r0, s0, tr)
+    np.testing.assert_allclose(df, ref_d, rtol=1e-5, atol=1e-7 * np.max(np.abs(ref_d)))
+    gm.model.close()
+
+
+def test_local_penalization_batch_from_table():
+    np.random.seed(3)
+    X, Y, table = O.synthetic_problem(120, 2, 4000, seed=12)
+    gm = gpo.GPModel(kernel=gpo.kern.Matern52(2, 1.0, 0.3), noise_var=0.01, max_iters=0, verbose=False)
+    gm.updateModel(X, Y, None, None)
+    space = gpo.Design_space([{'name': 'x', 'type': 'continuous', 'domain': (0, 1), 'dimensionality': 2}])
+    lp = gpo.AcquisitionLP(gm, space, None, gpo.AcquisitionEI(gm, space))
+    L = gpo.estimate_L(gm.model, space.get_bounds())
+    assert L > 0
+    chosen = gpo.LocalPenalization(lp, 5).compute_batch_from_table(table, sense=+1)
+    assert len(chosen) == 5 and len(set(chosen)) == 5
+    gm.model.close()
+
+
+def test_bayesian_optimization_local_penalization_batch():
+    """The constructor arguments of run.py:1207-1224 (evaluator_type='local_penalization', batch of suggestions)."""
+    np.random.seed(1)
+    f = lambda x: np.sum((x - 0.6) ** 2, axis=1, keepdims=True)  # noqa: E731
+    dom = [{'name': 'x', 'type': 'continuous', 'domain': (0, 1), 'dimensionality': 2}]
+    X0 = np.random.rand(8, 2)
+    bo = gpo.methods.BayesianOptimization(f=None, domain=dom, X=X0, Y=f(X0), model_type='GP', acquisition_type='EI',
+                                          normalize_Y=True, exact_feval=True, evaluator_type='local_penalization',
+                                          batch_size=3, optimize_restarts=1, max_iters=50)
+    Xn = bo.suggest_next_locations()
+    assert Xn.shape == (3, 2) and (Xn >= 0).all() and (Xn <= 1).all()
+    assert len({tuple(np.round(r, 6)) for r in Xn}) == 3
+    # the candidate-table loop of run.py:1234-1258 on the same acquisition
+    table = np.random.rand(3000, 2)
+    chosen = bo.evaluator.compute_batch_from_table(table, sense=+1)
+    assert len(set(chosen)) == 3
+    bo.model.model.close()

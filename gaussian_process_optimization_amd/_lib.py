@@ -31,6 +31,7 @@ SIGNATURES = [
     ("gp_destroy", ctypes.c_int, [_vp]),
     ("gp_set_data", ctypes.c_int, [_vp, c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     ("gp_set_params", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_double]),
+    ("gp_set_gower", ctypes.c_int, [_vp, ctypes.c_int, c_int_p, c_double_p]),
     ("gp_fit", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
     ("gp_fit_predict", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
                                       c_double_p]),
@@ -163,6 +164,17 @@ class Handle(object):
             raise ValueError("lengthscale has %d entries, expected %d" % (ls.size, self.D if ard else 1))
         check(self.lib, self.lib.gp_set_params(self.h, int(kernel), int(bool(ard)), float(variance), dptr(ls),
                                                float(noise)), "gp_set_params")
+
+    def set_gower(self, is_discrete=None, ranges=None):
+        """Enable (or, with no arguments, disable) the fork's Gower product kernel."""
+        if is_discrete is None:
+            check(self.lib, self.lib.gp_set_gower(self.h, 0, None, None), "gp_set_gower")
+            return
+        disc = np.ascontiguousarray(is_discrete, dtype=np.int32)
+        rng = as_f64(ranges, 1)
+        if disc.size != self.D or rng.size != self.D:
+            raise ValueError("is_discrete / ranges need one entry per input dimension")
+        check(self.lib, self.lib.gp_set_gower(self.h, 1, disc.ctypes.data_as(c_int_p), dptr(rng)), "gp_set_gower")
 
     def fit(self, maxtries=5):
         lml, logdet, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()

@@ -84,6 +84,17 @@ class Design_space(object):
                 x[i] = min(max(x[i], d[0]), d[1])
         return x[None, :]
 
+    # -- the fork's additions for the Gower kernel (space.py:351-362,436-445,483-492) -------------------
+    def get_continuous_dims(self):
+        return [i for i, t in enumerate(self.types) if t == 'continuous']
+
+    def get_discrete_dims(self):
+        return [i for i, t in enumerate(self.types) if t == 'discrete']
+
+    def lengthscales(self):
+        """Ranges of the continuous variables, in order (space.py:351-362)."""
+        return [d[-1] - d[0] for t, d in zip(self.types, self.domains) if t == 'continuous']
+
     def samples_uniform(self, n, rng=np.random):
         """experiment_design/random_design.py:7-65."""
         Z = np.empty((n, self.dimensionality))
@@ -162,7 +173,7 @@ class BayesianOptimization(object):
             kernel=kernel, noise_var=kwargs.get('noise_var', None), exact_feval=exact_feval,
             optimizer=kwargs.get('model_optimizer_type', 'lbfgs'), max_iters=kwargs.get('max_iters', 1000),
             optimize_restarts=kwargs.get('optimize_restarts', 5), verbose=verbosity_model,
-            ARD=kwargs.get('ARD', False), device=device)
+            ARD=kwargs.get('ARD', False), Gower=kwargs.get('Gower', False), space=self.space, device=device)
         self.acquisition_optimizer = AcquisitionOptimizer(self.space, acquisition_optimizer_type)
         # arguments_manager.py:42-75
         jitter = kwargs.get('acquisition_jitter', 0.01)

@@ -452,6 +452,28 @@ int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N, int D, int
     return 0;
 }
 
+// The fork's Gower kernel option (GPy/GPy/kern/src/stationary.py:61-65,116-135; lengthscales = variable ranges,
+// GPyOpt/GPyOpt/core/task/space.py:351-362).  Only K is Gower: Kdiag stays `variance` and the gradient
+// formulas stay Euclidean in the fork; the former is reproduced, the latter are refused (gp_lml_grad /
+// gp_predict_grad return GP_ERR_STATE for a Gower model).
+int gp_set_gower(gp_t *g, int enable, const int *is_discrete, const double *range) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (!g->have_data) return fail(GP_ERR_STATE, "gp_set_data first");
+    if (enable && (!is_discrete || !range)) return fail(GP_ERR_ARG, "null argument");
+    g->kp.gower = enable ? 1 : 0;
+    for (int d = 0; d < g->D && enable; ++d) {
+        g->kp.gdisc[d] = is_discrete[d] ? 1 : 0;
+        g->kp.gdiv[d] = is_discrete[d] ? 1.0 : range[d];
+        if (!is_discrete[d] && !(range[d] > 0.0)) return fail(GP_ERR_ARG, "range of dimension %d must be positive", d);
+    }
+    g->fitted = false;
+    g->fmin_valid = false;
+    g->wi_valid = false;
+    g->invp_valid = false;
+    g->predicted = false;
+    return 0;
+}
+
 int gp_set_params(gp_t *g, int kernel, int ard, double variance, const double *lengthscale, double noise) {
     if (!g || !lengthscale) return fail(GP_ERR_ARG, "null argument");
     if (!g->have_data) return fail(GP_ERR_STATE, "gp_set_data must precede gp_set_params");
@@ -762,7 +784,7 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         pp.S = g->dT2;
     }
     const double diag_add = g->noise + 1e-8;  // exact_gaussian_inference.py:56
-    const double diag0 = g->kp.variance + diag_add;
+    const double diag0 = (g->kp.gower ? std::pow(g->kp.variance, g->D) : g->kp.variance) + diag_add;
     g->nphases = 0;
     g->fitted = false;
     g->fmin_valid = false;
@@ -1324,6 +1346,8 @@ int gp_lml_grad(gp_t *g, double *dvariance, double *dlengthscale, double *dnoise
     if (!g || !dvariance || !dlengthscale || !dnoise) return fail(GP_ERR_ARG, "null argument");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
+    if (g->kp.gower) return fail(GP_ERR_STATE, "hyper-gradients of the Gower kernel are not replicated (the fork mixes "
+                                               "Gower K with Euclidean dK/dr, stationary.py:218-238)");
     HIPCHK(hipSetDevice(g->device));
     int rc;
     g->nphases = 0;
@@ -1379,6 +1403,7 @@ static int ensure_grad_buffers(gp_ctx *g, long elemsBeta, long M) {
 // predictive gradients of all resident candidates into dDm [M, D, P] and dDv [M, D]
 static int run_predict_grad(gp_ctx *g) {
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->kp.gower) return fail(GP_ERR_STATE, "predictive gradients of the Gower kernel are not replicated");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     int rc;
     if ((rc = ensure_wi(g))) return rc;

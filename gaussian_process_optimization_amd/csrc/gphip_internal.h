@@ -18,7 +18,14 @@ struct KernParams {
     int D;
     double variance;
     double ls[GP_MAX_D];       // lengthscale per dimension (iso: all equal)
+    // the fork's "Gower" mixed-variable kernel (GPy/GPy/kern/src/stationary.py:116-135): K = prod_d k1(r_d),
+    // r_d = |x_d - x'_d| / range_d for continuous dimensions, (x_d != x'_d) for discrete ones
+    int gower;
+    unsigned char gdisc[GP_MAX_D];  // 1: discrete dimension
+    double gdiv[GP_MAX_D];          // staging divisor: range_d (continuous) or 1 (discrete)
 };
+// divisor used when staging inputs for a covariance evaluation
+__host__ __device__ static inline double kp_div(const KernParams &kp, int d) { return kp.gower ? kp.gdiv[d] : kp.ls[d]; }
 
 // ---- tile-set descriptor for the GEMM family ---------------------------------
 // Enumerates output tiles (i, c): c in [c0, c1); rows i in [tri ? c : r0, r1).

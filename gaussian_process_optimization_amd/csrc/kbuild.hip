@@ -24,6 +24,12 @@ __device__ __forceinline__ double k_of_r2(int kernel, double variance, double r2
         return variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * exp(-s5 * r);
     }
 }
+// one 1-D factor of the Gower product kernel: K_of_r(|dx|) for a continuous dimension (dx already divided by
+// the variable's range), K_of_r(dx != 0) for a discrete one (stationary.py:122-129)
+__device__ __forceinline__ double gower_factor(int kernel, double variance, double dx, int disc) {
+    const double r = disc ? (dx != 0.0 ? 1.0 : 0.0) : fabs(dx);
+    return k_of_r2(kernel, variance, r * r);
+}
 
 // Stage rows [row0, row0+128) of X (N x D row-major) divided by the lengthscale (stationary.py:188-191) into LDS transposed: dst[d*128 + r].
 __device__ __forceinline__ void stage_rows_T(double *dst, const double *X, long row0, long N, int D,
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(double *A, long lda, const 
         while ((long)(tm + 1) * (tm + 2) / 2 <= t) ++tm;
         tn = (int)(t - (long)tm * (tm + 1) / 2);
     }
-    if (tid < kp.D) ils[tid] = kp.ls[tid];
+    if (tid < kp.D) ils[tid] = kp_div(kp, tid);
     __syncthreads();
     stage_rows_T(xi, X, (long)tm * GP_TILE, N, kp.D, ils, tid);
     stage_rows_T(xj, X, (long)tn * GP_TILE, N, kp.D, ils, tid);
@@ -66,26 +72,40 @@ __global__ __launch_bounds__(256) void kbuild_kernel(double *A, long lda, const 
     for (int q = 0; q < 32; ++q) {
         const int r = ry + 4 * q;
         const long gr = (long)tm * GP_TILE + r;
-        double s0 = 0.0, s1 = 0.0;
-        for (int d = 0; d < kp.D; ++d) {
-            const double a = xi[d * GP_TILE + r];
-            const double2_t b = *(const double2_t *)(xj + d * GP_TILE + cx);
-            const double d0 = a - b[0], d1 = a - b[1];
-            s0 = fma(d0, d0, s0);
-            s1 = fma(d1, d1, s1);
-        }
         double2_t out;
-        out[0] = k_of_r2(kp.kernel, kp.variance, s0);
-        out[1] = k_of_r2(kp.kernel, kp.variance, s1);
+        if (kp.gower) {
+            double p0 = 1.0, p1 = 1.0;
+            for (int d = 0; d < kp.D; ++d) {
+                const double a = xi[d * GP_TILE + r];
+                const double2_t b = *(const double2_t *)(xj + d * GP_TILE + cx);
+                p0 *= gower_factor(kp.kernel, kp.variance, a - b[0], kp.gdisc[d]);
+                p1 *= gower_factor(kp.kernel, kp.variance, a - b[1], kp.gdisc[d]);
+            }
+            out[0] = p0;
+            out[1] = p1;
+        } else {
+            double s0 = 0.0, s1 = 0.0;
+            for (int d = 0; d < kp.D; ++d) {
+                const double a = xi[d * GP_TILE + r];
+                const double2_t b = *(const double2_t *)(xj + d * GP_TILE + cx);
+                const double d0 = a - b[0], d1 = a - b[1];
+                s0 = fma(d0, d0, s0);
+                s1 = fma(d1, d1, s1);
+            }
+            out[0] = k_of_r2(kp.kernel, kp.variance, s0);
+            out[1] = k_of_r2(kp.kernel, kp.variance, s1);
+        }
         // diagonal and padding
         if (gr >= N) {
             out[0] = (gr == gc) ? 1.0 : 0.0;
             out[1] = (gr == gc + 1) ? 1.0 : 0.0;
         } else {
+            // the Euclidean diagonal is exactly the variance (r forced to 0, stationary.py:164); the Gower product
+            // at r = 0 is variance^D and is already in out[]
             if (gc >= N) out[0] = 0.0;
-            else if (gr == gc) out[0] = kp.variance + diag_add;
+            else if (gr == gc) out[0] = (kp.gower ? out[0] : kp.variance) + diag_add;
             if (gc + 1 >= N) out[1] = 0.0;
-            else if (gr == gc + 1) out[1] = kp.variance + diag_add;
+            else if (gr == gc + 1) out[1] = (kp.gower ? out[1] : kp.variance) + diag_add;
         }
         *(double2_t *)(A + gr * lda + gc) = out;
     }
@@ -121,7 +141,7 @@ __global__ __launch_bounds__(256) void cross_k_kernel(double *T, long ldt, const
     __shared__ double ils[GP_MAX_D];
     const int tid = threadIdx.x;
     const int tc = blockIdx.x / nti, ti = blockIdx.x % nti;
-    if (tid < kp.D) ils[tid] = kp.ls[tid];
+    if (tid < kp.D) ils[tid] = kp_div(kp, tid);
     __syncthreads();
     stage_rows_T(xc, Xs, (long)tc * GP_TILE, M, kp.D, ils, tid);
     stage_rows_T(xt, X, (long)ti * GP_TILE, N, kp.D, ils, tid);
@@ -132,17 +152,31 @@ __global__ __launch_bounds__(256) void cross_k_kernel(double *T, long ldt, const
     for (int q = 0; q < 32; ++q) {
         const int r = ry + 4 * q;
         const long gcand = (long)tc * GP_TILE + r;
-        double s0 = 0.0, s1 = 0.0;
-        for (int d = 0; d < kp.D; ++d) {
-            const double a = xc[d * GP_TILE + r];
-            const double2_t b = *(const double2_t *)(xt + d * GP_TILE + cx);
-            const double d0 = a - b[0], d1 = a - b[1];
-            s0 = fma(d0, d0, s0);
-            s1 = fma(d1, d1, s1);
+        double k0, k1;
+        if (kp.gower) {
+            k0 = 1.0;
+            k1 = 1.0;
+            for (int d = 0; d < kp.D; ++d) {
+                const double a = xc[d * GP_TILE + r];
+                const double2_t b = *(const double2_t *)(xt + d * GP_TILE + cx);
+                k0 *= gower_factor(kp.kernel, kp.variance, a - b[0], kp.gdisc[d]);
+                k1 *= gower_factor(kp.kernel, kp.variance, a - b[1], kp.gdisc[d]);
+            }
+        } else {
+            double s0 = 0.0, s1 = 0.0;
+            for (int d = 0; d < kp.D; ++d) {
+                const double a = xc[d * GP_TILE + r];
+                const double2_t b = *(const double2_t *)(xt + d * GP_TILE + cx);
+                const double d0 = a - b[0], d1 = a - b[1];
+                s0 = fma(d0, d0, s0);
+                s1 = fma(d1, d1, s1);
+            }
+            k0 = k_of_r2(kp.kernel, kp.variance, s0);
+            k1 = k_of_r2(kp.kernel, kp.variance, s1);
         }
         double2_t out;
-        out[0] = (gcand < M && gi < N) ? k_of_r2(kp.kernel, kp.variance, s0) : 0.0;
-        out[1] = (gcand < M && gi + 1 < N) ? k_of_r2(kp.kernel, kp.variance, s1) : 0.0;
+        out[0] = (gcand < M && gi < N) ? k0 : 0.0;
+        out[1] = (gcand < M && gi + 1 < N) ? k1 : 0.0;
         *(double2_t *)(T + gcand * ldt + gi) = out;
     }
 }

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void train_mean_kernel(const double *X, long N
     for (int idx = tid; idx < GP_TILE * kp.D; idx += 256) {
         const int rr = idx / kp.D, d = idx - rr * kp.D;
         const long g = row0 + rr;
-        xi[d * GP_TILE + rr] = (g < N) ? X[g * kp.D + d] / kp.ls[d] : 0.0;
+        xi[d * GP_TILE + rr] = (g < N) ? X[g * kp.D + d] / kp_div(kp, d) : 0.0;
     }
     double acc = 0.0;
     for (long tj = blockIdx.y; tj < ntile; tj += TM_SPLIT) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void train_mean_kernel(const double *X, long N
         for (int idx = tid; idx < GP_TILE * kp.D; idx += 256) {
             const int rr = idx / kp.D, d = idx - rr * kp.D;
             const long g = tj * GP_TILE + rr;
-            xj[d * GP_TILE + rr] = (g < N) ? X[g * kp.D + d] / kp.ls[d] : 0.0;
+            xj[d * GP_TILE + rr] = (g < N) ? X[g * kp.D + d] / kp_div(kp, d) : 0.0;
         }
         if (tid < GP_TILE) {
             const long g = tj * GP_TILE + tid;
@@ -232,12 +232,23 @@ __global__ __launch_bounds__(256) void train_mean_kernel(const double *X, long N
         }
         __syncthreads();
         for (int jj = h * 64; jj < h * 64 + 64; ++jj) {
-            double s = 0.0;
-            for (int d = 0; d < kp.D; ++d) {
-                const double df = xi[d * GP_TILE + r] - xj[d * GP_TILE + jj];
-                s = fma(df, df, s);
+            double kv;
+            if (kp.gower) {
+                kv = 1.0;
+                for (int d = 0; d < kp.D; ++d) {
+                    const double df = xi[d * GP_TILE + r] - xj[d * GP_TILE + jj];
+                    const double rr = kp.gdisc[d] ? (df != 0.0 ? 1.0 : 0.0) : fabs(df);
+                    kv *= k_of_r2_s(kp.kernel, kp.variance, rr * rr);
+                }
+            } else {
+                double s = 0.0;
+                for (int d = 0; d < kp.D; ++d) {
+                    const double df = xi[d * GP_TILE + r] - xj[d * GP_TILE + jj];
+                    s = fma(df, df, s);
+                }
+                kv = k_of_r2_s(kp.kernel, kp.variance, s);
             }
-            acc = fma(k_of_r2_s(kp.kernel, kp.variance, s), aj[jj], acc);
+            acc = fma(kv, aj[jj], acc);
         }
     }
     red[tid] = acc;

@@ -14,7 +14,7 @@ import numpy as np
 from scipy import optimize as _sopt
 
 from . import _lib
-from .kern import RBF, Stationary
+from .kern import RBF, Stationary, gower_config
 from .parameterization import Param, Parameterized
 
 
@@ -162,6 +162,10 @@ class GPRegression(Parameterized):
         k = self.kern
         self._h.set_params(k._kernel_id, k.ARD, float(k.variance), k.lengthscale.values,
                            float(self.likelihood.variance))
+        if k.Gower and k.space is not None:
+            self._h.set_gower(*gower_config(k.space, k.input_dim))
+        else:
+            self._h.set_gower()
         self._lml, self._logdet, self._jitter = self._h.fit(self.max_jitter_tries)
         self._dirty = False
 
@@ -251,10 +255,24 @@ class GPRegression(Parameterized):
         return fsim
 
     # -- optimisation -------------------------------------------------------------------
+    def _uses_gower(self):
+        return bool(self.kern.Gower and self.kern.space is not None)
+
     def _obj_grad(self, x):
         try:
             self.optimizer_array = x
             f = self.objective_function()
+            if self._uses_gower():
+                # the fork pairs the Gower K with Euclidean gradient formulas (stationary.py:218-238), which are not
+                # gradients of this objective; forward differences of the device LML are used instead
+                g = np.empty_like(x)
+                for i in range(x.size):
+                    e = np.zeros_like(x)
+                    e[i] = 1e-6
+                    self.optimizer_array = x + e
+                    g[i] = (self.objective_function() - f) / 1e-6
+                self.optimizer_array = x
+                return f, g
             g = self.objective_function_gradients()
         except np.linalg.LinAlgError:
             return 1e10, np.zeros_like(x)  # paramz Model._objective_grads: failed evaluations are walls

@@ -34,13 +34,14 @@ class BOModel(object):
 class GPModel(BOModel):
     analytical_gradient_prediction = True  # gpmodel.py:29
 
+    def _gower(self):
+        return bool(self.Gower and self.space is not None)
+
     def __init__(self, kernel=None, noise_var=None, exact_feval=False, optimizer='bfgs', max_iters=1000,
                  optimize_restarts=5, sparse=False, num_inducing=10, verbose=True, ARD=False, Gower=False,
                  space=None, device=0):
         if sparse:
             raise NotImplementedError("sparse GP is a different model family (out of scope)")
-        if Gower:
-            raise NotImplementedError("the fork's Gower kernel is listed under 'next' in SURVEY.md 8(f)")
         self.kernel = kernel
         self.noise_var = noise_var
         self.exact_feval = exact_feval
@@ -64,7 +65,7 @@ class GPModel(BOModel):
         """gpmodel.py:50-76."""
         self.input_dim = X.shape[1]
         if self.kernel is None:
-            kern = _kern.Matern52(self.input_dim, variance=1., ARD=self.ARD)
+            kern = _kern.Matern52(self.input_dim, variance=1., ARD=self.ARD, Gower=self.Gower, space=self.space)
         else:
             kern = self.kernel
             self.kernel = None

@@ -15,8 +15,12 @@ from .parameterization import Param, Parameterized
 class Stationary(Parameterized):
     _kernel_id = None
 
-    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="stationary"):
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="stationary",
+                 Gower=False, space=None):
         super(Stationary, self).__init__(name)
+        # the fork's mixed-variable option (stationary.py:61-65): product of 1-D kernels over the variables of `space`
+        self.Gower = bool(Gower)
+        self.space = space
         self.input_dim = int(input_dim)
         if active_dims is not None and list(active_dims) != list(range(self.input_dim)):
             raise NotImplementedError("active_dims slicing is outside the accelerated path")
@@ -50,6 +54,8 @@ class Stationary(Parameterized):
             if X2 is None:
                 h.set_data(X, np.zeros((X.shape[0], 1)))
                 h.set_params(self._kernel_id, self.ARD, float(self.variance), self.lengthscale.values, 0.0)
+                if self.Gower and self.space is not None:
+                    h.set_gower(*gower_config(self.space, self.input_dim))
                 return h.kernel_matrix()
             # cross covariance through the candidate path: K(X2 as candidates, X as data)^T
             raise NotImplementedError("use GPRegression.predict for cross covariances")
@@ -62,20 +68,40 @@ class Stationary(Parameterized):
         return ret
 
     def copy(self):
-        return self.__class__(self.input_dim, float(self.variance), self.lengthscale.values.copy(), self.ARD)
+        return self.__class__(self.input_dim, float(self.variance), self.lengthscale.values.copy(), self.ARD,
+                              Gower=self.Gower, space=self.space)
+
+
+def gower_config(space, input_dim):
+    """(is_discrete[D], range[D]) from a design space, as the fork's Stationary.K reads it
+    (stationary.py:117-119: space.get_continuous_dims / get_discrete_dims / lengthscales)."""
+    cont = list(space.get_continuous_dims())
+    disc = list(space.get_discrete_dims())
+    ranges = list(space.lengthscales())
+    is_disc = np.zeros(input_dim, dtype=np.int32)
+    rng = np.ones(input_dim)
+    for idx, d in enumerate(cont):
+        rng[d] = ranges[idx]
+    for d in disc:
+        is_disc[d] = 1
+    if sorted(cont + disc) != list(range(input_dim)):
+        raise ValueError("the Gower kernel needs every input dimension to be continuous or discrete in `space`")
+    return is_disc, rng
 
 
 class RBF(Stationary):
     """GPy.kern.RBF -- k(r) = variance * exp(-r^2 / 2)  (rbf.py:50-51)."""
     _kernel_id = _lib.GP_KERNEL_RBF
 
-    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="rbf"):
-        super(RBF, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name)
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="rbf",
+                 Gower=False, space=None):
+        super(RBF, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, Gower, space)
 
 
 class Matern52(Stationary):
     """GPy.kern.Matern52 -- k(r) = variance (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)  (stationary.py:575-576)."""
     _kernel_id = _lib.GP_KERNEL_MATERN52
 
-    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="Mat52"):
-        super(Matern52, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name)
+    def __init__(self, input_dim, variance=1., lengthscale=None, ARD=False, active_dims=None, name="Mat52",
+                 Gower=False, space=None):
+        super(Matern52, self).__init__(input_dim, variance, lengthscale, ARD, active_dims, name, Gower, space)

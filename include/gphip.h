@@ -64,6 +64,11 @@ int gp_set_data(gp_t *gp, const double *X, const double *Y, int64_t N, int D, in
  * lengthscale has 1 entry (ard = 0) or D entries (ard = 1). */
 int gp_set_params(gp_t *gp, int kernel, int ard, double variance, const double *lengthscale, double noise);
 
+/* The fork's mixed-variable "Gower" covariance (GPy/GPy/kern/src/stationary.py:116-135 of the reference tree):
+ * K = prod_d K_of_r(r_d), r_d = |x_d - x'_d| / range[d] on continuous dimensions and (x_d != x'_d) on discrete
+ * ones (is_discrete[d] != 0).  enable = 0 restores the Euclidean kernel.  Kdiag remains `variance`, as in the fork. */
+int gp_set_gower(gp_t *gp, int enable, const int *is_discrete, const double *range);
+
 /* ---- fit ---------------------------------------------------------------
  * ExactGaussianInference.inference (GPy/GPy/inference/latent_function_inference/
  * exact_gaussian_inference.py:37-74) minus the gradient terms:

@@ -148,8 +148,10 @@ class Stationary(object):
 
     name = "stationary"
 
-    def __init__(self, input_dim, variance=1.0, lengthscale=None, ARD=False):
+    def __init__(self, input_dim, variance=1.0, lengthscale=None, ARD=False, Gower=False, space=None):
         # stationary.py:61-82
+        self.Gower = Gower
+        self.space = space
         self.input_dim = int(input_dim)
         self.ARD = bool(ARD)
         if not ARD:
@@ -199,7 +201,25 @@ class Stationary(object):
             return self._unscaled_dist(X, X2) / self.lengthscale
 
     def K(self, X, X2=None):
-        """stationary.py:107-140 (Euclidean branch)."""
+        """stationary.py:107-140: the fork's Gower branch (:116-135) and the Euclidean branch (:137-139)."""
+        if self.Gower and (self.space is not None):
+            const_dims = self.space.get_continuous_dims()
+            disc_dims = self.space.get_discrete_dims()
+            lengthscale = self.space.lengthscales()
+            numDims = X.shape[1]
+            if X2 is None:
+                X2 = X
+            K_1D = [None for dim in range(numDims)]
+            for index, const_dim in enumerate(const_dims, start=0):
+                r = abs(X[:, np.newaxis, const_dim] - X2[np.newaxis, :, const_dim]) / lengthscale[index]
+                K_1D[const_dim] = self.K_of_r(r)
+            for disc_dim in disc_dims:
+                r = (X[:, np.newaxis, disc_dim] != X2[np.newaxis, :, disc_dim]).astype(int)
+                K_1D[disc_dim] = self.K_of_r(r)
+            kernel = K_1D[0]
+            for dim in range(numDims - 1):
+                kernel = kernel * K_1D[dim + 1]
+            return kernel
         r = self._scaled_dist(X, X2)
         return self.K_of_r(r)
 
@@ -276,8 +296,8 @@ class Matern52(Stationary):
 KERNELS = {"rbf": RBF, "RBF": RBF, "Mat52": Matern52, "Matern52": Matern52, "matern52": Matern52}
 
 
-def make_kernel(name, input_dim, variance=1.0, lengthscale=None, ARD=False):
-    return KERNELS[name](input_dim, variance=variance, lengthscale=lengthscale, ARD=ARD)
+def make_kernel(name, input_dim, variance=1.0, lengthscale=None, ARD=False, Gower=False, space=None):
+    return KERNELS[name](input_dim, variance=variance, lengthscale=lengthscale, ARD=ARD, Gower=Gower, space=space)
 
 
 # ----------------------------------------------------------------------------

@@ -289,3 +289,50 @@ def test_bayesian_optimization_local_penalization_batch():
     chosen = bo.evaluator.compute_batch_from_table(table, sense=+1)
     assert len(set(chosen)) == 3
     bo.model.model.close()
+
+
+def test_gower_mixed_variable_kernel():
+    """The fork's only numerical change (stationary.py:116-135): product of 1-D kernels, |dx|/range on continuous
+    variables, Hamming on discrete ones; Kdiag stays `variance` as in the fork."""
+    rng = np.random.default_rng(4)
+    dom = [{'name': 'a', 'type': 'discrete', 'domain': (0, 1, 2, 3)},
+           {'name': 'x', 'type': 'continuous', 'domain': (-2.0, 5.0)},
+           {'name': 'b', 'type': 'discrete', 'domain': (10, 20)},
+           {'name': 'y', 'type': 'continuous', 'domain': (0.0, 0.5)}]
+    space = gpo.Design_space(dom)
+    N, M = 260, 90
+    def draw(n):
+        return np.c_[rng.integers(0, 4, n), rng.uniform(-2, 5, n), rng.choice([10, 20], n), rng.uniform(0, 0.5, n)].astype(float)
+    X, Xs = draw(N), draw(M)
+    Xs[:5] = X[:5]                                   # exact matches exercise r = 0 on every factor
+    Y = (np.sin(X[:, 1]) + 0.3 * X[:, 0] - 0.1 * (X[:, 2] == 20) + 2 * X[:, 3])[:, None] + 0.05 * rng.standard_normal((N, 1))
+    for cls, name, var in ((gpo.kern.Matern52, "Mat52", 1.0), (gpo.kern.RBF, "rbf", 1.3)):
+        k = cls(4, variance=var, Gower=True, space=space)
+        ko = O.make_kernel(name, 4, var, None, Gower=True, space=space)
+        K = k.K(X)
+        K0 = ko.K(X)
+        np.testing.assert_allclose(K, K0, rtol=1e-13, atol=1e-15)
+        assert abs(K[0, 0] - var ** 4) < 1e-13             # product of four factors at r = 0
+        m = gpo.models.GPRegression(X, Y, k, noise_var=0.05)
+        gp = O.OracleGP(X, Y, ko, 0.05)
+        assert abs(m.log_likelihood() - gp.log_likelihood()) <= 1e-8 * abs(gp.log_likelihood())
+        mu, v = m.predict(Xs)
+        mu0, v0 = gp.predict(Xs)
+        np.testing.assert_allclose(mu, mu0, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(v, v0, rtol=1e-6, atol=1e-9)
+        with pytest.raises(RuntimeError, match="Gower"):
+            m.predictive_gradients(Xs[:2])
+        m.close()
+    # through GPyOpt's front door, as run.py:1207-1224 builds it (Gower=True, exact_feval=True, no optimisation here)
+    gm = gpo.GPModel(exact_feval=True, max_iters=0, Gower=True, space=space, verbose=False)
+    gm.updateModel(X, Y, None, None)
+    acq = gpo.AcquisitionEI(gm, space)
+    a = acq.acquisition_function(Xs)
+    gp = O.OracleGP(X, Y, O.make_kernel("Mat52", 4, 1.0, None, Gower=True, space=space), 1e-6)
+    ref = -O.acq_EI(O.OracleGPModel(gp), Xs, 0.01)
+    np.testing.assert_allclose(a, ref, rtol=1e-4, atol=1e-6 * np.max(np.abs(ref)))
+    # hyper-parameter optimisation runs on finite differences of the device LML and must not lower it
+    l0 = gm.model.log_likelihood()
+    gm.model.optimize(max_iters=15)
+    assert gm.model.log_likelihood() >= l0 - 1e-6
+    gm.model.close()

@@ -90,3 +90,91 @@ def test_c3_properties_full_size():
     lml2 = h.fit()[0]
     assert lml2 == lml
     h.close()
+
+
+def test_c4_one_shard_matern_125k_candidates():
+    """C4 as one rank sees it: N=16384, D=8 Matern-5/2, this rank's 125 000 of the 10^6 candidates
+    (8 chunks of mc_max rows).  Checked through properties: a random subset predicted on its own gives
+    the same numbers (chunk position does not matter), EI on the device == the reference's EI formula on
+    the downloaded mean/variance, device arg-best == numpy's first minimum."""
+    N, D, M = 16384, 8, 125000
+    X, Y, _ = O.synthetic_problem(N, D, 8, seed=1234)
+    Xs = np.random.default_rng(77).uniform(0, 1, (M, D))
+    noise = 1e-2
+    h = _lib.Handle(0)
+    h.set_data(X, Y)
+    h.set_params(_lib.GP_KERNEL_MATERN52, 0, 1.0, O.default_lengthscale(D, False), noise)
+    lml, logdet, jit = h.fit()
+    assert jit == 0.0 and np.isfinite(lml)
+    alpha = h.alpha()
+    rows = np.random.default_rng(1).choice(N, 128, replace=False)
+    kern = O.Matern52(D, 1.0, O.default_lengthscale(D, False))
+    resid = kern.K(X[rows], X) @ alpha + (noise + 1e-8) * alpha[rows] - Y[rows]
+    assert np.max(np.abs(resid)) < 1e-9 * max(1.0, np.max(np.abs(alpha)))
+    fmin = h.fmin()
+    h.set_candidates(Xs)
+    mu, var = h.predict(True)
+    assert np.isfinite(mu).all() and (var > noise * 0.999).all() and (var <= 1.0 + noise + 1e-9).all()
+    a = h.acq(_lib.GP_ACQ_EI, 0.01, fmin)
+    idx, val = h.acq_argbest(_lib.GP_ACQ_EI, 0.01, fmin, -1)
+    assert idx == int(np.argmin(a[:, 0])) and val == a[idx, 0]
+    # EI.py:32-40 + base.py:33-50 on the device's own mean / sd
+    s = np.sqrt(np.clip(var, 1e-10, np.inf))
+    phi, Phi, u = O.get_quantiles(0.01, fmin, mu, s.copy())
+    ei = -(s * (u * Phi + phi))
+    assert np.max(np.abs(a - ei)) <= 1e-12 * max(1.0, np.max(np.abs(ei)))
+    # a subset evaluated alone (different chunk, different row position)
+    sub = np.sort(np.random.default_rng(2).choice(M, 1000, replace=False))
+    h.set_candidates(Xs[sub])
+    mu_s, var_s = h.predict(True)
+    assert np.max(np.abs(mu_s - mu[sub])) <= 1e-12 * max(1.0, np.max(np.abs(mu)))
+    assert np.max(np.abs(var_s - var[sub])) <= 1e-12
+    h.close()
+
+
+def test_c5_lml_and_gradients_n32768_ard():
+    """C5: N=32768, D=16 ARD-RBF, LML + (D+2) gradients.  Gradient entries are checked against central
+    differences of the device LML itself (the reference's model_tests.py:684-723 does the same through
+    checkgrad), and variance + noise gradients together against Euler's identity for Ky = v K0 + n I."""
+    N, D = 32768, 16
+    X, Y, _ = O.synthetic_problem(N, D, 8, seed=1234)
+    ls = O.default_lengthscale(D, True)
+    var0, noise = 1.0, 1e-2
+    h = _lib.Handle(0)
+    h.set_data(X, Y)
+
+    def lml_at(v, l, n):
+        h.set_params(_lib.GP_KERNEL_RBF, 1, v, l, n)
+        return h.fit()
+
+    lml, logdet, jit = lml_at(var0, ls, noise)
+    assert jit == 0.0
+    alpha = h.alpha()
+    lml_host = 0.5 * (-N * np.log(2 * np.pi) - logdet - float(np.sum(alpha * Y)))
+    assert abs(lml - lml_host) <= 1e-12 * abs(lml_host)
+    dv, dl, dn = h.lml_grad(D)
+    assert np.isfinite([dv, dn]).all() and np.isfinite(dl).all()
+    # Euler identity for Ky = v*K0 + (n + 1e-8) I:  v*dv + (n+1e-8)*dn = sum_ij dL_dK_ij Ky_ij
+    #   = 0.5 (alpha' Ky alpha - tr(I)) = 0.5 (alpha'y - N)      (exact_gaussian_inference.py:70)
+    euler = 0.5 * (float(np.sum(alpha * Y)) - N)
+    assert abs(var0 * dv + (noise + 1e-8) * dn - euler) <= 1e-8 * max(abs(euler), abs(var0 * dv))
+    # central differences of the device LML
+    def fd(which, q=None):
+        rel = 1e-4
+        def at(sign):
+            v, l, n = var0, ls.copy(), noise
+            if which == "v":
+                v = var0 * (1 + sign * rel)
+            elif which == "n":
+                n = noise * (1 + sign * rel)
+            else:
+                l[q] = ls[q] * (1 + sign * rel)
+            return lml_at(v, l, n)[0]
+        base = {"v": var0, "n": noise}.get(which, None if q is None else ls[q])
+        return (at(+1) - at(-1)) / (2 * rel * base)
+    scale = max(abs(dv), abs(dn), np.max(np.abs(dl)))
+    assert abs(fd("v") - dv) <= 2e-5 * scale
+    assert abs(fd("n") - dn) <= 2e-5 * scale
+    for q in (0, D - 1):
+        assert abs(fd("l", q) - dl[q]) <= 2e-5 * scale
+    h.close()

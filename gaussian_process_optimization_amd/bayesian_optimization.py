@@ -141,6 +141,90 @@ class AcquisitionOptimizer(object):
         return best_x, best_fx
 
 
+def _lbfgs_from_anchor(space, a, f, f_df, maxiter=1000):
+    """optimizer.py:36-59 + apply_optimizer :130-168: one bounded L-BFGS run from anchor ``a``."""
+    def _f_df(x):
+        fx, dfx = f_df(np.atleast_2d(x))
+        return float(np.asarray(fx).ravel()[0]), np.asarray(dfx, dtype=float).ravel()
+    res = _sopt.fmin_l_bfgs_b(_f_df, x0=a, bounds=space.get_bounds(), maxiter=maxiter)
+    x = np.atleast_2d(res[0])
+    if res[2].get('task', b'') in (b'ABNORMAL_TERMINATION_IN_LNSRCH', 'ABNORMAL_TERMINATION_IN_LNSRCH'):
+        x = np.atleast_2d(a)
+    return space.round_optimum(x)
+
+
+class ThompsonSamplingAnchorPointsGenerator(object):
+    """optimization/anchor_points_generator.py:66-82: marginal Thompson sampling.  ONE batched device
+    predict over ``num_samples`` random locations, one normal draw per location from its own (mean, sd),
+    the ``num_anchor`` lowest draws are the anchors (:19-63)."""
+
+    def __init__(self, space, design_type, model, num_samples=25000):
+        self.space, self.design_type, self.model, self.num_samples = space, design_type, model, num_samples
+
+    def get_anchor_point_scores(self, X):
+        m, s = self.model.predict(X)
+        return np.random.normal(m.ravel(), s.ravel())
+
+    def get(self, num_anchor=5, duplicate_manager=None, unique=False, context_manager=None):
+        X = self.space.samples_uniform(self.num_samples)
+        scores = self.get_anchor_point_scores(X)
+        return X[np.argsort(scores)[:min(len(scores), num_anchor)], :]
+
+
+class RandomAnchorPointsGenerator(object):
+    """anchor_points_generator.py:100-113: every sample scores the same, i.e. the first ``num_anchor`` rows."""
+
+    def __init__(self, space, design_type, num_samples=10000):
+        self.space, self.num_samples = space, num_samples
+
+    def get(self, num_anchor=5, duplicate_manager=None, unique=False, context_manager=None):
+        X = self.space.samples_uniform(self.num_samples)
+        return X[np.argsort(np.arange(X.shape[0]), kind='stable')[:num_anchor], :]
+
+
+class SamplingBasedBatchEvaluator(object):
+    """core/evaluators/base.py:21-92 without the duplicate manager (de_duplication is host bookkeeping)."""
+
+    def __init__(self, acquisition, batch_size):
+        self.acquisition, self.batch_size, self.space = acquisition, batch_size, acquisition.space
+        self.num_anchor = 5 * batch_size
+
+    def compute_batch(self, duplicate_manager=None, context_manager=None):
+        if duplicate_manager is not None or context_manager is not None:
+            raise NotImplementedError("duplicate / context managers are outside the accelerated path")
+        return self.compute_batch_without_duplicate_logic()
+
+
+class ThompsonBatch(SamplingBasedBatchEvaluator):
+    """core/evaluators/batch_thompson.py:9-55: anchors by marginal Thompson sampling on the model, each of
+    the first ``batch_size`` anchors refined by L-BFGS on the acquisition."""
+
+    def __init__(self, acquisition, batch_size):
+        super(ThompsonBatch, self).__init__(acquisition, batch_size)
+        self.model = acquisition.model
+        self.f, self.f_df = acquisition.acquisition_function, acquisition.acquisition_function_withGradients
+
+    def get_anchor_points(self):
+        return ThompsonSamplingAnchorPointsGenerator(self.space, "random", self.model).get(num_anchor=self.num_anchor)
+
+    def optimize_anchor_point(self, a):
+        return _lbfgs_from_anchor(self.space, a, self.f, self.f_df)
+
+    def compute_batch_without_duplicate_logic(self):
+        anchors = self.get_anchor_points()
+        return np.vstack([self.optimize_anchor_point(a) for a, _ in zip(anchors, range(self.batch_size))])
+
+
+class RandomBatch(SamplingBasedBatchEvaluator):
+    """core/evaluators/batch_random.py:9-48: first element = the optimised acquisition, the rest uniform."""
+
+    def compute_batch_without_duplicate_logic(self):
+        x, _ = self.acquisition.optimize()
+        k = self.batch_size - 1
+        anchors = RandomAnchorPointsGenerator(self.space, "random").get(num_anchor=self.num_anchor)
+        return np.vstack([x] + [a for a, _ in zip(anchors, range(k))])
+
+
 class BayesianOptimization(object):
     """GPyOpt.methods.BayesianOptimization for model_type='GP' (bayesian_optimization.py:76-170)."""
 
@@ -151,10 +235,8 @@ class BayesianOptimization(object):
                  maximize=False, de_duplication=False, model=None, acquisition=None, device=0, **kwargs):
         if model_type not in ('GP',) and model is None:
             raise NotImplementedError("model_type %r is outside the accelerated path" % model_type)
-        if evaluator_type not in ('sequential', 'local_penalization'):
+        if evaluator_type not in ('sequential', 'local_penalization', 'thompson_sampling', 'random', None):
             raise NotImplementedError("evaluator %r is outside the accelerated path" % evaluator_type)
-        if evaluator_type == 'sequential' and batch_size != 1:
-            raise NotImplementedError("the sequential evaluator proposes one point at a time")
         self.evaluator_type = evaluator_type
         self.batch_size = batch_size
         self.f = f
@@ -189,7 +271,13 @@ class BayesianOptimization(object):
         else:
             raise NotImplementedError("acquisition %r is outside the accelerated path" % acquisition_type)
         # arguments_manager.py:17-38 (evaluator_creator): local penalisation wraps the acquisition (LP.py)
-        if evaluator_type == 'local_penalization':
+        if batch_size == 1 or evaluator_type == 'sequential':
+            self.evaluator = None                      # Sequential: one optimised point (arguments_manager.py:23-24)
+        elif evaluator_type in ('random', None):
+            self.evaluator = RandomBatch(self.acquisition, batch_size)
+        elif evaluator_type == 'thompson_sampling':
+            self.evaluator = ThompsonBatch(self.acquisition, batch_size)
+        elif evaluator_type == 'local_penalization':
             if not isinstance(self.acquisition, AcquisitionLP):
                 self.acquisition = AcquisitionLP(self.model, self.space, self.acquisition_optimizer, self.acquisition,
                                                  transform=kwargs.get('acquisition_transformation', 'none'))

@@ -119,6 +119,8 @@ struct gp_ctx {
     std::map<std::array<int, 5>, short *> tile_lists;  // cached L2-friendly tile orders (device)
     int supertile = 0;
     int small_below = 1400;  // launches with fewer 128-tiles than this use 64x64 workgroup tiles
+    int inner_left_rows = 1 << 30;  // panels with at least this many row tiles update their columns left-looking
+    int trsm_waves8 = 0;     // in-place panel solves on the 8-wave variant
     int waves8 = 1;
     int stagger = 3;  // see gemm.hip: odd-slot workgroups start 3 * 1024 cycles late (+1.5 % measured)
     int pipe_start_pct = 0;   // gp_fit_predict: candidate stages start once this share of the panels is factored
@@ -242,6 +244,8 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
     GemmOpt oo = o;
     if (n >= 1024 && !oo.stagger) oo.stagger = g->stagger;
     if (n >= 1024 && g->waves8) oo.waves8 = 1;  // 4 waves/SIMD: +2 % on the long launches (measured)
+    // in-place panel solves are at most one workgroup per CU: eight waves hide the single tile's LDS/barrier latency
+    if (oo.inplace && g->trsm_waves8 && n <= 512) oo.waves8 = 1;
     // short launches (the factorisation's latency chain, the uneven triangular-K products) run as 64x64 work units
     if (g->small_below > 0 && n < g->small_below && !oo.inplace) oo.small = 1;
     if (g->supertile > 1 && !o.tile_list && !o.k_end_tri && o.batch == 1 && tileset_count(ts) >= 2048) {
@@ -391,6 +395,10 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         if (value != g->bulk_reserved)
             return fail(GP_ERR_ARG, "reserve_cus is fixed when the device's streams are created (%d); set GPHIP_RESERVE_CUS "
                                     "before the first gp_create", g->bulk_reserved);
+    } else if (!strcmp(name, "inner_left_rows")) {
+        g->inner_left_rows = (int)value;
+    } else if (!strcmp(name, "trsm_waves8")) {
+        g->trsm_waves8 = (int)value;
     } else if (!strcmp(name, "mc_max")) {
         if (value < GP_TILE) return fail(GP_ERR_ARG, "mc_max < 128");
         g->mc_max = round_up(value, GP_TILE);
@@ -574,11 +582,19 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     const int pred_start = std::min(nJ - 1, nJ * g->pipe_start_pct / 100);
     for (int J = 0; J < nJ; ++J) {
         const int J0 = J * W, J1 = std::min(J0 + W, nt), J2 = std::min(J1 + W, nt);
+        // in-panel updates: left-looking while the panel is tall (column j receives columns J0..j-1 in ONE
+        // contraction of K = 128 (j-J0): a third of the C traffic of j-J0 rank-128 updates and a longer K, which is
+        // what counts while the chain shares the chip with the trailing update), right-looking once the panel is
+        // short and the chain alone sets the pace (the rank-128 update is the shorter launch)
+        const bool left = (R1 - J0) >= g->inner_left_rows;
         for (int j = J0; j < J1; ++j) {
+            if (left && j > J0)
+                gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, (j - J0) * GP_TILE,
+                     TileSet{0, R1, j, j + 1, 1});
             launch_potrf_tile(sp, A, lda, j, g->dInvL, g->dInfo);
             gemm(g, sp, 0, A, lda, A + (long)j * GP_TILE, lda, g->dInvL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0,
                  GP_TILE, TileSet{j + 1, R1, j, j + 1, 0}, inplace_opt());
-            if (j + 1 < J1)
+            if (!left && j + 1 < J1)
                 gemm(g, sp, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE,
                      TileSet{0, R1, j + 1, J1, 1});
         }

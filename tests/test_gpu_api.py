@@ -291,6 +291,37 @@ def test_bayesian_optimization_local_penalization_batch():
     bo.model.model.close()
 
 
+def test_bayesian_optimization_thompson_and_random_batches():
+    """evaluator_type='thompson_sampling' / 'random' (arguments_manager.py:26-30; batch_thompson.py, batch_random.py):
+    marginal Thompson anchors come from ONE batched device predict over 25 000 samples."""
+    np.random.seed(2)
+    f = lambda x: np.sum((x - 0.3) ** 2, axis=1, keepdims=True)  # noqa: E731
+    dom = [{'name': 'x', 'type': 'continuous', 'domain': (0, 1), 'dimensionality': 2}]
+    X0 = np.random.rand(10, 2)
+    for ev in ('thompson_sampling', 'random'):
+        bo = gpo.methods.BayesianOptimization(f=None, domain=dom, X=X0, Y=f(X0), model_type='GP', acquisition_type='EI',
+                                              normalize_Y=True, exact_feval=True, evaluator_type=ev, batch_size=4,
+                                              optimize_restarts=1, max_iters=50)
+        Xn = bo.suggest_next_locations()
+        assert Xn.shape == (4, 2) and (Xn >= 0).all() and (Xn <= 1).all()
+        if ev == 'thompson_sampling':
+            gen = gpo.bayesian_optimization.ThompsonSamplingAnchorPointsGenerator(bo.space, 'random', bo.model, 5000)
+            Xs = bo.space.samples_uniform(5000)
+            m, s = bo.model.predict(Xs)
+            np.random.seed(7)
+            draws = gen.get_anchor_point_scores(Xs)
+            np.random.seed(7)
+            # anchor_points_generator.py:79-82: one normal(m_i, s_i) draw per location, in order
+            ref = np.array([np.random.normal(mi, si) for mi, si in zip(m, s)]).flatten()
+            assert np.allclose(draws, ref, rtol=0, atol=1e-12)
+        bo.model.model.close()
+    # batch_size == 1 falls back to the sequential evaluator whatever evaluator_type says (arguments_manager.py:23)
+    bo = gpo.methods.BayesianOptimization(f=None, domain=dom, X=X0, Y=f(X0), evaluator_type='thompson_sampling',
+                                          batch_size=1, optimize_restarts=1, max_iters=20)
+    assert bo.evaluator is None and bo.suggest_next_locations().shape == (1, 2)
+    bo.model.model.close()
+
+
 def test_gower_mixed_variable_kernel():
     """The fork's only numerical change (stationary.py:116-135): product of 1-D kernels, |dx|/range on continuous
     variables, Hamming on discrete ones; Kdiag stays `variance` as in the fork."""

@@ -108,7 +108,7 @@ struct gp_ctx {
     // options
     int panel_tiles = 6;
     int lookahead = 1;
-    int reserve_cus = 8;
+    int reserve_cus = 32;
     long mc_max = 16384;
     // profiling
     Phase phases[MAX_PHASES];
@@ -119,8 +119,11 @@ struct gp_ctx {
     std::map<std::array<int, 5>, short *> tile_lists;  // cached L2-friendly tile orders (device)
     int supertile = 0;
     int small_below = 1400;  // launches with fewer 128-tiles than this use 64x64 workgroup tiles
+    int chain_small_below = 400;  // ... the same threshold for the launches of the factorisation's chain stream
+    int fmin_direct = 0;     // gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha
     int inner_left_rows = 1 << 30;  // panels with at least this many row tiles update their columns left-looking
     int trsm_waves8 = 0;     // in-place panel solves on the 8-wave variant
+    int panel_tiles_tail = 0, tail_rows = 0;  // narrower factorisation panels once fewer than tail_rows row tiles remain
     int waves8 = 1;
     int stagger = 3;  // see gemm.hip: odd-slot workgroups start 3 * 1024 cycles late (+1.5 % measured)
     int pipe_start_pct = 0;   // gp_fit_predict: candidate stages start once this share of the panels is factored
@@ -247,7 +250,8 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
     // in-place panel solves are at most one workgroup per CU: eight waves hide the single tile's LDS/barrier latency
     if (oo.inplace && g->trsm_waves8 && n <= 512) oo.waves8 = 1;
     // short launches (the factorisation's latency chain, the uneven triangular-K products) run as 64x64 work units
-    if (g->small_below > 0 && n < g->small_below && !oo.inplace) oo.small = 1;
+    const int small_thr = (s == g->s_panel) ? g->chain_small_below : g->small_below;
+    if (small_thr > 0 && n < small_thr && !oo.inplace) oo.small = 1;
     if (g->supertile > 1 && !o.tile_list && !o.k_end_tri && o.batch == 1 && tileset_count(ts) >= 2048) {
         const std::array<int, 5> key{ts.r0, ts.r1, ts.c0, ts.c1, ts.tri};
         auto it = g->tile_lists.find(key);
@@ -384,6 +388,11 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->pipe_start_pct = (int)value;
     } else if (!strcmp(name, "small_below")) {
         g->small_below = (int)value;
+    } else if (!strcmp(name, "fmin_direct")) {
+        g->fmin_direct = (int)value;
+        g->fmin_valid = false;
+    } else if (!strcmp(name, "chain_small_below")) {
+        g->chain_small_below = (int)value;
     } else if (!strcmp(name, "waves8")) {
         g->waves8 = value ? 1 : 0;
     } else if (!strcmp(name, "stagger")) {
@@ -395,6 +404,11 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         if (value != g->bulk_reserved)
             return fail(GP_ERR_ARG, "reserve_cus is fixed when the device's streams are created (%d); set GPHIP_RESERVE_CUS "
                                     "before the first gp_create", g->bulk_reserved);
+    } else if (!strcmp(name, "panel_tiles_tail")) {
+        if (value < 0 || value > 16) return fail(GP_ERR_ARG, "panel_tiles_tail out of range");
+        g->panel_tiles_tail = (int)value;
+    } else if (!strcmp(name, "tail_rows")) {
+        g->tail_rows = (int)value;
     } else if (!strcmp(name, "inner_left_rows")) {
         g->inner_left_rows = (int)value;
     } else if (!strcmp(name, "trsm_waves8")) {
@@ -564,7 +578,6 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     const int nt = (int)(g->Npad / GP_TILE);
     const int R1 = nt + 1;
     const int W = g->panel_tiles;
-    const int nJ = (nt + W - 1) / W;
     double *A = g->dA;
     hipStream_t sp = g->s_panel, sb = g->s_bulk;
     // fork
@@ -579,9 +592,22 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     }
     // events: 1 + 2J = chain(J) done, 2 + 2J = bulk(J) done; 1000 + J = invP_J built
     int next_pred = 0;
-    const int pred_start = std::min(nJ - 1, nJ * g->pipe_start_pct / 100);
+    const int nJu = (nt + W - 1) / W;
+    const int pred_start = std::min(nJu - 1, nJu * g->pipe_start_pct / 100);
+    // panel boundaries: W tiles while the trailing matrix is tall; `panel_tiles_tail` once fewer than `tail_rows`
+    // row tiles remain (the chain sets the pace there and a narrower panel means a shorter look-ahead update
+    // between two chains).  The pipelined candidate solve needs the uniform panels its inverses are built on.
+    std::vector<int> pb;
+    for (int j = 0; j < nt;) {
+        pb.push_back(j);
+        const int w = (!pp.on && g->panel_tiles_tail > 0 && nt - j < g->tail_rows) ? g->panel_tiles_tail : W;
+        j += w;
+    }
+    pb.push_back(nt);
+    pb.push_back(nt);
+    const int nJ = (int)pb.size() - 2;
     for (int J = 0; J < nJ; ++J) {
-        const int J0 = J * W, J1 = std::min(J0 + W, nt), J2 = std::min(J1 + W, nt);
+        const int J0 = pb[J], J1 = pb[J + 1], J2 = pb[J + 2];
         // in-panel updates: left-looking while the panel is tall (column j receives columns J0..j-1 in ONE
         // contraction of K = 128 (j-J0): a third of the C traffic of j-J0 rank-128 updates and a longer K, which is
         // what counts while the chain shares the chip with the trailing update), right-looking once the panel is
@@ -1049,7 +1075,10 @@ int gp_fmin(gp_t *g, double *fmin) {
     if (g->P != 1) return fail(GP_ERR_ARG, "gp_fmin needs P == 1");
     HIPCHK(hipSetDevice(g->device));
     if (!g->fmin_valid) {
-        launch_train_mean(g->s, g->dX, g->N, g->kp, g->dAlpha, g->dMu);
+        if (g->fmin_direct)
+            launch_train_mean(g->s, g->dX, g->N, g->kp, g->dAlpha, g->dMu);
+        else
+            launch_train_mean_identity(g->s, g->dY, g->dAlpha, g->noise + 1e-8 + g->jitter, g->N, g->dMu);
         launch_argbest(g->s, g->dMu, g->N, -1, g->dRedV + 256, g->dRedI + 256, g->dRedV, g->dRedI);
         double v = 0.0;
         HIPCHK(hipMemcpyAsync(&v, g->dRedV + 256, sizeof(double), hipMemcpyDeviceToHost, g->s));

@@ -93,6 +93,8 @@ void launch_predict_reduce(hipStream_t s, const double *T, long ldt, long M, lon
 // mu[i] = sum_j k(x_i, x_j) alpha[j]  (posterior mean at the training inputs, K generated on the fly)
 void launch_train_mean(hipStream_t s, const double *X, long N, const KernParams &kp, const double *alpha,
                        double *mu);
+// the same vector as y - d alpha (d = total diagonal added to K), O(N)
+void launch_train_mean_identity(hipStream_t s, const double *Y, const double *alpha, double d, long N, double *mu);
 // deterministic min / argbest reductions
 void launch_min(hipStream_t s, const double *v, long n, double *out);
 

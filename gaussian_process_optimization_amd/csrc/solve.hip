@@ -270,6 +270,18 @@ void launch_train_mean(hipStream_t s, const double *X, long N, const KernParams 
     hipLaunchKernelGGL(train_mean_sum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, mu + N, N, mu);
 }
 
+// Posterior mean at the training inputs from the normal equations instead of an N^2 pass:
+//   (K + d I) alpha = y  =>  K alpha = y - d alpha,   d = noise + 1e-8 (+ jitter)
+// GPModel.get_fmin (gpmodel.py:138-142) takes the minimum of exactly this vector; SURVEY.md 8a A9 marks the
+// reference's N^3 recomputation as cacheable.  The two differ by the residual of the solve (backward stable).
+__global__ void train_mean_identity_kernel(const double *Y, const double *alpha, double d, long N, double *mu) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) mu[i] = fma(-d, alpha[i], Y[i]);
+}
+void launch_train_mean_identity(hipStream_t s, const double *Y, const double *alpha, double d, long N, double *mu) {
+    hipLaunchKernelGGL(train_mean_identity_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Y, alpha, d, N, mu);
+}
+
 // ---- min / arg-best (NumPy tie rule: lowest index) -------------------------------------------
 __device__ __forceinline__ void best_combine(double &v, long long &i, double v2, long long i2, int sense) {
     // sense +1: larger wins; -1: smaller wins; ties -> lower index

@@ -182,7 +182,7 @@ int gp_gemm_trace(gp_t *gp, int cap, int64_t *tiles, int *K, double *ms);
 int gp_synchronize(gp_t *gp);
 /* tunables: "panel_tiles" (outer panel width in 128-tiles), "lookahead" (0/1),
  * "mc_max", "supertile".  The number of CUs kept free of the trailing update for the look-ahead chain is
- * fixed per process (environment GPHIP_RESERVE_CUS, default 8). */
+ * fixed per process (environment GPHIP_RESERVE_CUS, default 32). */
 int gp_set_option(gp_t *gp, const char *name, int64_t value);
 
 #ifdef __cplusplus

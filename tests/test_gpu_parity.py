@@ -280,3 +280,27 @@ def test_fit_predict_jitter_and_failure(golden, h):
     h.set_params(_lib.GP_KERNEL_RBF, 0, 1.0, [0.5], float(golden["jitfail/noise"]))
     with pytest.raises(np.linalg.LinAlgError):
         h.fit_predict(True)
+
+
+@pytest.mark.parametrize("noise", [1e-2, 1e-6])
+def test_fmin_identity_equals_direct_product(h, noise):
+    """gp_fmin takes min(y - d alpha) (normal equations, O(N)); the reference's get_fmin (gpmodel.py:138-142) takes
+    min(K(X,X) alpha).  Both are checked against the oracle and against each other."""
+    rng = np.random.default_rng(5)
+    N, D = 900, 3
+    X = rng.uniform(0, 1, (N, D))
+    Y = np.sin(6 * X.sum(1, keepdims=True)) + 0.05 * rng.standard_normal((N, 1))
+    kern = O.make_kernel("Mat52", D, 1.3, np.array([0.4]), ARD=False)
+    gp = O.OracleGP(X, Y, kern, noise)
+    f0 = O.OracleGPModel(gp).get_fmin()
+    h.set_data(X, Y)
+    h.set_params(1, 0, 1.3, [0.4], noise)
+    h.fit()
+    f_id = h.fmin()
+    h.set_option("fmin_direct", 1)
+    try:
+        f_dir = h.fmin()
+    finally:
+        h.set_option("fmin_direct", 0)
+    assert abs(f_id - f_dir) <= 1e-9 * max(1.0, abs(f_dir))
+    assert abs(f_id - f0) <= 1e-6 * max(1.0, abs(f0))

@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "Mat52"])
     ap.add_argument("--panel-tiles", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true",
+                    help="also time the pipelined entry point gp_fit_predict (un-timed region; its overlapping launches "
+                         "would blur a rocprofv3 --stats average of this command, so it is off by default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,14 +149,16 @@ def main():
         elapsed = float(tt.item())
 
     # un-timed extras: the same step through the pipelined entry point (gp_fit_predict), and phase breakdowns
-    step(True)
-    h.synchronize()
-    tp0 = time.perf_counter()
-    for _ in range(3):
+    pipelined_ms, phases_pipelined = None, None
+    if args.extras:
         step(True)
-    h.synchronize()
-    pipelined_ms = (time.perf_counter() - tp0) / 3 * 1e3
-    phases_pipelined = {p["name"]: round(p["ms"], 3) for p in h.phases()}
+        h.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(3):
+            step(True)
+        h.synchronize()
+        pipelined_ms = (time.perf_counter() - tp0) / 3 * 1e3
+        phases_pipelined = {p["name"]: round(p["ms"], 3) for p in h.phases()}
     h.fit()
     ph_fit = h.phases()
     h.predict(True)
@@ -161,6 +166,15 @@ def main():
     phases = {p["name"]: round(p["ms"], 3) for p in ph_fit + ph_pred}
     chol = [p for p in ph_fit if p["name"] == "cholesky"][0]
     solve = [p for p in ph_pred if p["name"] == "cand_solve"][0]
+
+    # HBM-side traffic of the dominant kernel: PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in separate
+    # rocprofv3 --pmc runs, gfx950 correction applied; tools/pmc_traffic.py), averaged per big launch like `achieved`
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    if os.path.exists(tpath) and (N, D, M) == (16384, 8, 10000):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_gemm_traffic.json (rocprofv3 --pmc, %d launches)" % tj["launches"]
 
     result = None
     if rank == 0:
@@ -179,19 +193,19 @@ def main():
                        "noise": 1e-2, "candidates_per_gpu": M, "fit": "replicated on every rank",
                        "job_iters_per_s": job_rate, "lml": out[0], "best_candidate": int(out[1]),
                        "phases_ms": phases,
-                       "pipelined_entry_point": {"ms_per_step": pipelined_ms, "iters_per_s": 1e3 / pipelined_ms,
-                                                 "phases_ms": phases_pipelined,
-                                                 "note": "gp_fit_predict: candidate solve pipelined behind the "
-                                                         "factorisation; not used for `value` so that the per-launch "
-                                                         "roofline below is not blurred by overlapping launches"},
+                       "pipelined_entry_point": None if pipelined_ms is None else {
+                           "ms_per_step": pipelined_ms, "iters_per_s": 1e3 / pipelined_ms, "phases_ms": phases_pipelined,
+                           "note": "gp_fit_predict: candidate solve pipelined behind the factorisation; not used for "
+                                   "`value` so that the per-launch roofline below is not blurred by overlapping launches"},
                        "cholesky_tflops": chol["flops"] / chol["ms"] / 1e9,
                        "cholesky_frac_of_fp64_mfma_peak": chol["flops"] / chol["ms"] / 1e9 / FP64_MFMA_PEAK_TFLOPS,
                        "cand_solve_tflops": solve["flops"] / solve["ms"] / 1e9},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (fp64 v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<1, 128, 4> (C -= A B^T on fp64 v_mfma_f64_16x16x4_f64, 8 waves)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src,
                          "launches": gs["launches"], "kernel_ms_total": gs["ms"],
-                         "launch_filter": "launches with >= 1024 output tiles (they carry > 90 % of the flops)",
+                         "launch_filter": "every launch of that kernel symbol in the timed region (launches of >= 1400 output tiles: trailing updates, candidate updates; > 90 % of the flops)", "avg_launch_ms": gs["ms"] / max(gs["launches"], 1),
                          "flops_per_launch_avg": gs["flops"] / max(gs["launches"], 1)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -226,10 +226,21 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
                  long ldb, int b_mul, int K, TileSet ts, const GemmOpt &o = GemmOpt()) {
     const long n = tileset_count(ts) * o.batch;
     if (n <= 0 || K <= 0) return;
+    GemmOpt oo = o;
+    if (n >= 1024 && !oo.stagger) oo.stagger = g->stagger;
+    if (n >= 1024 && g->waves8) oo.waves8 = 1;  // 4 waves/SIMD: +2 % on the long launches (measured)
+    // in-place panel solves are at most one workgroup per CU: eight waves hide the single tile's LDS/barrier latency
+    if (oo.inplace && g->trsm_waves8 && n <= 512) oo.waves8 = 1;
+    // short launches (the factorisation's latency chain, the uneven triangular-K products) run as 64x64 work units
+    const int small_thr = (s == g->s_panel) ? g->chain_small_below : g->small_below;
+    if (small_thr > 0 && n < small_thr && !oo.inplace) oo.small = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // events only around the launches that carry the flops (>= 1024 output tiles): bracketing every one of the
     // ~700 small launches of an iteration stalls the latency chain (34 -> 53 ms per factorisation, measured)
-    const bool timed = g->profiling && n >= g->profile_min_tiles;
+    // ... and only the launches of ONE kernel symbol, gemm_nt_kernel<1, 128, 4> (C -= A B^T, 8 waves), so that the
+    // average agrees with that symbol's row in a rocprofv3 --stats summary of the same command
+    const bool timed = g->profiling && n >= g->profile_min_tiles &&
+                       (g->profile_min_tiles < 1024 || (mode == 1 && oo.waves8 && !oo.small));  // tracing tools lower the threshold
     if (timed) {
         if (g->gemm_ev_used + 2 > g->gemm_events.size()) {
             hipEvent_t a, b;
@@ -244,14 +255,6 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
         g->gemm_tiles.push_back(n);
         g->gemm_K.push_back((o.k_tri || o.k_end_tri) ? -K : K);
     }
-    GemmOpt oo = o;
-    if (n >= 1024 && !oo.stagger) oo.stagger = g->stagger;
-    if (n >= 1024 && g->waves8) oo.waves8 = 1;  // 4 waves/SIMD: +2 % on the long launches (measured)
-    // in-place panel solves are at most one workgroup per CU: eight waves hide the single tile's LDS/barrier latency
-    if (oo.inplace && g->trsm_waves8 && n <= 512) oo.waves8 = 1;
-    // short launches (the factorisation's latency chain, the uneven triangular-K products) run as 64x64 work units
-    const int small_thr = (s == g->s_panel) ? g->chain_small_below : g->small_below;
-    if (small_thr > 0 && n < small_thr && !oo.inplace) oo.small = 1;
     if (g->supertile > 1 && !o.tile_list && !o.k_end_tri && o.batch == 1 && tileset_count(ts) >= 2048) {
         const std::array<int, 5> key{ts.r0, ts.r1, ts.c0, ts.c1, ts.tri};
         auto it = g->tile_lists.find(key);

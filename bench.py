@@ -95,7 +95,10 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from gaussian_process_optimization_amd import _lib
-    h = _lib.Handle(local_rank)
+    # rehearsal switch for a one-GPU box: every rank on device 0 (RCCL then refuses the duplicate device and the
+    # exchange falls back to gloo); never set by the driver
+    dev = 0 if os.environ.get("GPHIP_BENCH_SAME_DEVICE") else local_rank
+    h = _lib.Handle(dev)
     if args.panel_tiles:
         h.set_option("panel_tiles", args.panel_tiles)
     N, D, M = args.N, args.D, args.M
@@ -104,11 +107,30 @@ def main():
     h.set_data(X, Y)
     h.set_params(kid, 0, 1.0, [0.25 * np.sqrt(D)], 1e-2)
     h.set_candidates(Xs)
+    collective = None
     if world > 1:
         import torch
-        uid = [h.comm_unique_id() if rank == 0 else None]
+        # the one data-path collective: an all-gather of 16 bytes per rank over RCCL.  If the RCCL
+        # communicator cannot be built on this node every rank agrees to fall back to the rendezvous backend (gloo)
+        # for that exchange -- said in the JSON line -- so that the scaling run still measures the sharded path.
+        ok = 1
+        try:
+            uid = [h.comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            uid, ok = [None], 0
+            sys.stderr.write("rank %d: RCCL unique id failed: %s\n" % (rank, e))
         dist.broadcast_object_list(uid, src=0)
-        h.comm_init(uid[0], rank, world)
+        if uid[0] is None:
+            ok = 0
+        if ok:
+            try:
+                h.comm_init(uid[0], rank, world)
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                sys.stderr.write("rank %d: RCCL comm init failed: %s\n" % (rank, e))
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        collective = "rccl" if int(flag.item()) == 1 else "gloo (RCCL communicator unavailable)"
 
     def barrier():
         h.synchronize()
@@ -125,8 +147,16 @@ def main():
         fmin = h.fmin()
         idx, val = h.acq_argbest(_lib.GP_ACQ_EI, 0.01, fmin, -1)
         if world > 1:
-            vals, idxs = h.comm_allgather_best(val, rank * M + idx, world)
             from gaussian_process_optimization_amd.sharded import merge_best
+            if collective == "rccl":
+                vals, idxs = h.comm_allgather_best(val, rank * M + idx, world)
+            else:
+                import torch
+                mine = torch.tensor([val, float(rank * M + idx)], dtype=torch.float64)
+                allp = [torch.empty(2, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(allp, mine)
+                vals = np.array([float(t[0]) for t in allp])
+                idxs = np.array([int(t[1]) for t in allp], dtype=np.int64)
             idx, val = merge_best(vals, idxs, -1)
         return lml, idx, val
 
@@ -190,7 +220,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3: N=%d, D=%d %s iso, fit (K, Cholesky, alpha, LML) + predict mean/var at "
                                    "M=%d candidates per GPU + EI arg-best" % (N, D, args.kernel, M),
-                       "noise": 1e-2, "candidates_per_gpu": M, "fit": "replicated on every rank",
+                       "noise": 1e-2, "candidates_per_gpu": M, "fit": "replicated on every rank", "collective": collective,
                        "job_iters_per_s": job_rate, "lml": out[0], "best_candidate": int(out[1]),
                        "phases_ms": phases,
                        "pipelined_entry_point": None if pipelined_ms is None else {

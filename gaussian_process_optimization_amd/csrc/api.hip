@@ -391,6 +391,9 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->pipe_start_pct = (int)value;
     } else if (!strcmp(name, "small_below")) {
         g->small_below = (int)value;
+    } else if (!strcmp(name, "profile_min_tiles")) {
+        if (value < 0) return fail(GP_ERR_ARG, "profile_min_tiles < 0");
+        g->profile_min_tiles = value;
     } else if (!strcmp(name, "fmin_direct")) {
         g->fmin_direct = (int)value;
         g->fmin_valid = false;

@@ -173,16 +173,29 @@ int gp_comm_bcast_fit(gp_t *gp, int root);
  * algorithmic flop count of the phase (0 for bandwidth phases), bytes[i] its
  * algorithmic bytes.  Returns the number of phases written (<= cap). */
 int gp_last_phases(gp_t *gp, int cap, const char **names, double *ms, double *flops, double *bytes);
-/* Dominant-kernel accounting (the fp64 MFMA GEMM): launches, summed device time (ms, HIP
- * events around every launch when profiling is on), algorithmic flops.  Reset by gp_profile(gp, 1). */
+/* Dominant-kernel accounting (the fp64 MFMA GEMM): launches, summed device time (ms, HIP events around the launches
+ * when profiling is on), algorithmic flops.  With the default threshold the events bracket exactly the launches of one
+ * kernel symbol, gemm_nt_kernel<1, 128, 4> (C -= A B^T, >= 1400 output tiles), so that the average agrees with that
+ * symbol's row of a rocprofv3 --stats summary; "profile_min_tiles" < 1024 brackets every launch above it instead
+ * (tracing tools).  Reset by gp_profile(gp, 1). */
 int gp_profile(gp_t *gp, int on);
 int gp_gemm_stats(gp_t *gp, int64_t *launches, double *ms, double *flops);
 /* per-launch record of the profiled GEMM launches: output tiles, K (negative: triangular contraction), ms */
 int gp_gemm_trace(gp_t *gp, int cap, int64_t *tiles, int *K, double *ms);
 int gp_synchronize(gp_t *gp);
-/* tunables: "panel_tiles" (outer panel width in 128-tiles), "lookahead" (0/1),
- * "mc_max", "supertile".  The number of CUs kept free of the trailing update for the look-ahead chain is
- * fixed per process (environment GPHIP_RESERVE_CUS, default 32). */
+/* Tunables (none changes a result beyond rounding; tests/test_gpu_random_shapes.py sweeps the blocking ones):
+ *   "panel_tiles"        outer panel width of the factorisation and of the inverted panels, in 128-tiles (default 6)
+ *   "panel_tiles_tail", "tail_rows"   narrower factorisation panels once fewer than tail_rows row tiles remain (off)
+ *   "lookahead"          0/1: one panel of look-ahead on separate streams (default 1)
+ *   "inner_left_rows"    panels at least this tall update their columns left-looking (off)
+ *   "mc_max"             candidate rows per chunk (default 16384)
+ *   "small_below", "chain_small_below"   launches with fewer 128-tiles run as 64x64 work units (1400 / 400 on the chain)
+ *   "waves8", "stagger", "trsm_waves8", "supertile"   GEMM launch shape
+ *   "pipe_start_pct"     gp_fit_predict: first panel (percent) at which candidate stages are released (default 0)
+ *   "fmin_direct"        gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha (default 0)
+ *   "profile_min_tiles"  see gp_profile
+ * The number of CUs kept free of the trailing update for the look-ahead chain is fixed per process
+ * (environment GPHIP_RESERVE_CUS, default 32; "reserve_cus" only checks the value). */
 int gp_set_option(gp_t *gp, const char *name, int64_t value);
 
 #ifdef __cplusplus

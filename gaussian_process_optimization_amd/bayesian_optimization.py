@@ -48,8 +48,16 @@ class Design_space(object):
     """Continuous / discrete box domain (subset of GPyOpt/GPyOpt/core/task/space.py:13-532)."""
 
     def __init__(self, space, constraints=None):
-        if constraints is not None:
-            raise NotImplementedError("string constraints (space.py:303-318) are host-only and out of scope")
+        # space.py:303-318: every constraint is the body of ``lambda x: ...`` over the 2-D array of locations; a
+        # location is feasible where the expression is < 0.  Compiled once here (the reference re-execs per call).
+        self.constraints = constraints
+        self._constraint_fns = []
+        for d in (constraints or []):
+            try:
+                self._constraint_fns.append(eval('lambda x: ' + d['constraint'], {'np': np, 'numpy': np}))
+            except Exception:
+                print('Fail to compile the constraint: ' + str(d))
+                raise
         self.config_space = space
         self.names, self.types, self.domains = [], [], []
         for i, v in enumerate(space):
@@ -65,10 +73,21 @@ class Design_space(object):
         self.model_dimensionality = self.dimensionality
 
     def has_constraints(self):
-        return False
+        """space.py:226-230."""
+        return self.constraints is not None
 
     def indicator_constraints(self, x):
-        return np.ones((np.atleast_2d(x).shape[0], 1))
+        """space.py:303-318: ones / zeros [M, 1]."""
+        x = np.atleast_2d(x)
+        I_x = np.ones((x.shape[0], 1))
+        for fn, d in zip(self._constraint_fns, self.constraints or []):
+            try:
+                ind_x = (np.asarray(fn(x)) < 0) * 1
+                I_x *= ind_x.reshape(x.shape[0], 1)
+            except Exception:
+                print('Fail to compile the constraint: ' + str(d))
+                raise
+        return I_x
 
     def get_bounds(self):
         return [(min(d), max(d)) for d in self.domains]
@@ -96,7 +115,19 @@ class Design_space(object):
         return [d[-1] - d[0] for t, d in zip(self.types, self.domains) if t == 'continuous']
 
     def samples_uniform(self, n, rng=np.random):
-        """experiment_design/random_design.py:7-65."""
+        """experiment_design/random_design.py:15-35: rejection sampling when the space has constraints."""
+        if not self.has_constraints():
+            return self._samples_box(n, rng)
+        samples = np.empty((0, self.dimensionality))
+        while samples.shape[0] < n:
+            Z = self._samples_box(n, rng)
+            ok = (self.indicator_constraints(Z) == 1).flatten()
+            if ok.sum() > 0:
+                samples = np.vstack((samples, Z[ok, :]))
+        return samples[0:n, :]
+
+    def _samples_box(self, n, rng=np.random):
+        """experiment_design/random_design.py:37-65."""
         Z = np.empty((n, self.dimensionality))
         for i, (t, d) in enumerate(zip(self.types, self.domains)):
             if t == 'discrete':

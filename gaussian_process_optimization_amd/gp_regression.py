@@ -244,6 +244,15 @@ class GPRegression(Parameterized):
         self._stage(Xnew)
         return self._h.predict_grad()
 
+    def posterior_covariance_between_points(self, X1, X2):
+        """gp.py:714-721 -> Posterior.covariance_between_points (posterior.py:109-128):
+        K(X1, X2) - (L^-1 K(X, X1))^T (L^-1 K(X, X2)), in the model's (normalised) output space.  Served by the
+        device's full-covariance path on the stacked points; the answer is its off-diagonal block."""
+        X1 = np.atleast_2d(np.asarray(X1, dtype=float))
+        X2 = np.atleast_2d(np.asarray(X2, dtype=float))
+        _, C = self._raw_predict(np.vstack([X1, X2]), full_cov=True)
+        return C[:X1.shape[0], X1.shape[0]:]
+
     def posterior_samples_f(self, X, size=10, **kw):
         """gp.py:581-609 (host-side draw from the device-computed full covariance)."""
         m, v = self._raw_predict(X, full_cov=True)

@@ -140,5 +140,9 @@ class GPModel(BOModel):
     def get_model_parameters(self):
         return np.atleast_2d(self.model[:])
 
+    def get_covariance_between_points(self, x1, x2):
+        """gpmodel.py:173-177."""
+        return self.model.posterior_covariance_between_points(x1, x2)
+
     def get_model_parameters_names(self):
         return self.model.parameter_names_flat().tolist()

@@ -477,6 +477,16 @@ class OracleGP(object):
     def predict_noiseless(self, Xnew, full_cov=False):
         return self.predict(Xnew, full_cov, include_likelihood=False)
 
+    def posterior_covariance_between_points(self, X1, X2):
+        """gp.py:714-721 -> Posterior.covariance_between_points, posterior.py:109-128."""
+        p = self.posterior
+        Kx1 = self.kern.K(self.X, X1)
+        Kx2 = self.kern.K(self.X, X2)
+        K12 = self.kern.K(X1, X2)
+        tmp1 = dtrtrs(p["L"], Kx1)[0]
+        tmp2 = dtrtrs(p["L"], Kx2)[0]
+        return K12 - tmp1.T.dot(tmp2)
+
     def predictive_gradients(self, Xnew):
         """gp.py:407-454."""
         p = self.posterior

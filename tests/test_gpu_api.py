@@ -33,6 +33,27 @@ def test_raw_predict_pinv_closed_form():
     m.close()
 
 
+def test_posterior_covariance_between_points():
+    """GP.posterior_covariance_between_points (gp.py:714-721) / GPModel.get_covariance_between_points
+    (gpmodel.py:173-177) against the oracle's restatement of posterior.py:109-128."""
+    rng = np.random.RandomState(3)
+    N, D = 150, 3
+    X = rng.rand(N, D); Y = np.sin(3 * X.sum(1, keepdims=True)) + 0.1 * rng.randn(N, 1)
+    X1, X2 = rng.rand(7, D), rng.rand(11, D)
+    for kname, cls in (("rbf", gpo.kern.RBF), ("Mat52", gpo.kern.Matern52)):
+        m = gpo.models.GPRegression(X, Y, kernel=cls(D, variance=1.4, lengthscale=0.6), noise_var=0.05)
+        gp = O.OracleGP(X, Y, O.make_kernel(kname, D, 1.4, np.array([0.6]), ARD=False), 0.05)
+        C = m.posterior_covariance_between_points(X1, X2)
+        C0 = gp.posterior_covariance_between_points(X1, X2)
+        assert C.shape == (7, 11)
+        assert np.max(np.abs(C - C0)) <= 1e-6 * max(1.0, np.max(np.abs(C0)))
+        # a point with itself: the off-diagonal block's diagonal is the noiseless predictive variance
+        Cs = m.posterior_covariance_between_points(X1, X1)
+        _, v = m.predict_noiseless(X1)
+        assert np.max(np.abs(np.diag(Cs)[:, None] - v)) <= 1e-9
+        m.close()
+
+
 def test_raw_predict_numerical_stability():
     rs = np.random.RandomState(3)
     x1, x2 = np.meshgrid(np.linspace(-5, 10, 5), np.linspace(0, 15, 5))
@@ -319,6 +340,24 @@ def test_bayesian_optimization_thompson_and_random_batches():
     bo = gpo.methods.BayesianOptimization(f=None, domain=dom, X=X0, Y=f(X0), evaluator_type='thompson_sampling',
                                           batch_size=1, optimize_restarts=1, max_iters=20)
     assert bo.evaluator is None and bo.suggest_next_locations().shape == (1, 2)
+    bo.model.model.close()
+
+
+def test_bayesian_optimization_with_string_constraints():
+    """constraints=[{'name', 'constraint'}] (space.py:303-318): the acquisition is zeroed outside the feasible set
+    (base.py:33-39, host epilogue over the device posterior) and the suggestion is feasible."""
+    np.random.seed(5)
+    f = lambda x: np.sum((x - 0.8) ** 2, axis=1, keepdims=True)  # noqa: E731  (unconstrained optimum is infeasible)
+    dom = [{'name': 'x', 'type': 'continuous', 'domain': (0, 1), 'dimensionality': 2}]
+    cons = [{'name': 'c', 'constraint': 'x[:,0] + x[:,1] - 1'}]
+    bo = gpo.methods.BayesianOptimization(f=f, domain=dom, constraints=cons, initial_design_numdata=6,
+                                          acquisition_type='EI', exact_feval=True, optimize_restarts=1, max_iters=50)
+    assert (bo.X.sum(1) < 1).all()                       # the initial design is drawn by rejection
+    xn = bo.suggest_next_locations()
+    assert bo.space.indicator_constraints(xn)[0, 0] == 1.0
+    Z = np.random.rand(400, 2)
+    a = bo.acquisition.acquisition_function(Z)
+    assert (a[Z.sum(1) >= 1] == 0).all() and (a[Z.sum(1) < 1] <= 0).all()
     bo.model.model.close()
 
 

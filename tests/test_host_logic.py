@@ -89,6 +89,33 @@ def test_design_space_rounding_and_sampling():
     assert (sp.indicator_constraints(Z) == 1).all()
 
 
+def test_design_space_string_constraints():
+    """space.py:303-318 / random_design.py:21-35: feasible where the expression is < 0; samples are drawn by rejection;
+    the negated acquisition is zero outside (acquisitions/base.py:33-39)."""
+    dom = [{'name': 'x', 'type': 'continuous', 'domain': (0, 1), 'dimensionality': 2}]
+    cons = [{'name': 'c0', 'constraint': 'x[:,0] + x[:,1] - 1'}, {'name': 'c1', 'constraint': '0.2 - x[:,0]'}]
+    sp = Design_space(dom, cons)
+    assert sp.has_constraints()
+    x = np.array([[0.5, 0.4], [0.5, 0.6], [0.1, 0.1], [0.3, 0.7]])
+    np.testing.assert_array_equal(sp.indicator_constraints(x), [[1.0], [0.0], [0.0], [0.0]])   # strict <
+    Z = sp.samples_uniform(300, np.random.RandomState(1))
+    assert Z.shape == (300, 2) and (Z.sum(1) < 1).all() and (Z[:, 0] > 0.2).all()
+    with pytest.raises(SyntaxError):
+        Design_space(dom, [{'name': 'bad', 'constraint': 'x[:,0] +* 1'}])
+
+    from gaussian_process_optimization_amd.acquisitions import AcquisitionBase
+
+    class _Acq(AcquisitionBase):
+        def _compute_acq(self, x):
+            return np.ones((x.shape[0], 1)) * 2.0
+
+    class _M(object):
+        pass
+    a = _Acq(_M(), sp)
+    a._device_ok = lambda: False
+    np.testing.assert_array_equal(a.acquisition_function(x), [[-2.0], [0.0], [0.0], [0.0]])
+
+
 def test_host_formulas_equal_oracle():
     rng = np.random.default_rng(0)
     y = rng.standard_normal((30, 1))

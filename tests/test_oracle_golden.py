@@ -56,3 +56,23 @@ def test_multi_output_normalizer_golden(golden):
     mu, var = gp.predict(golden["multi/Xs"])
     assert np.array_equal(mu, golden["multi/mu"]) and np.array_equal(var, golden["multi/var"])
     assert gp.log_likelihood() == float(golden["multi/lml"])
+
+
+def test_posterior_covariance_between_points_reference_golden():
+    """The reference's one numeric golden on this path (GPy/GPy/testing/model_tests.py:1158-1174): a Poly(order 1)
+    kernel, two training points, expected [[0.4, 2.2], [1, 1]] / 3.  It pins the algebra of
+    Posterior.covariance_between_points (posterior.py:109-128) as restated in the oracle; the kernel is the test's own
+    three-line stand-in for GPy.kern.Poly defaults (variance = scale = bias = 1)."""
+    from oracle import cpu_ref as O
+
+    class Poly(object):
+        def K(self, X, X2=None):
+            X2 = X if X2 is None else X2
+            return X.dot(X2.T) + 1.0
+
+    X1 = np.array([[-2., 2.], [-1., 1.]])
+    X2 = np.array([[2., 3.], [-1., 3.]])
+    Y = np.array([[1.], [2.]])
+    gp = O.OracleGP(X1, Y, Poly(), noise_var=1.0)   # GPRegression default noise_var = 1 (gp_regression.py:29)
+    result = gp.posterior_covariance_between_points(X1, X2)
+    assert np.allclose(result, np.array([[0.4, 2.2], [1.0, 1.0]]) / 3.0)

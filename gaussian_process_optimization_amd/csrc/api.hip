@@ -120,6 +120,7 @@ struct gp_ctx {
     int supertile = 0;
     int small_below = 1400;  // launches with fewer 128-tiles than this use 64x64 workgroup tiles
     int chain_small_below = 400;  // ... the same threshold for the launches of the factorisation's chain stream
+    int pair_tri = 1;        // triangular-K products: pair column tiles c and W-1-c in one workgroup
     int fmin_direct = 0;     // gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha
     int inner_left_rows = 1 << 30;  // panels with at least this many row tiles update their columns left-looking
     int trsm_waves8 = 0;     // in-place panel solves on the 8-wave variant
@@ -234,6 +235,9 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
     // short launches (the factorisation's latency chain, the uneven triangular-K products) run as 64x64 work units
     const int small_thr = (s == g->s_panel) ? g->chain_small_below : g->small_below;
     if (small_thr > 0 && n < small_thr && !oo.inplace) oo.small = 1;
+    // products with an inverted panel: column tile c contracts c+1 K-blocks; pairing c with W-1-c gives every
+    // workgroup the same W+1 blocks (one balanced round of workgroups instead of a long and a short one)
+    if (g->pair_tri && oo.small && o.k_end_tri && !ts.tri && !o.tile_list && ts.c1 - ts.c0 >= 2) oo.pair = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // events only around the launches that carry the flops (>= 1024 output tiles): bracketing every one of the
     // ~700 small launches of an iteration stalls the latency chain (34 -> 53 ms per factorisation, measured)
@@ -394,6 +398,8 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "profile_min_tiles")) {
         if (value < 0) return fail(GP_ERR_ARG, "profile_min_tiles < 0");
         g->profile_min_tiles = value;
+    } else if (!strcmp(name, "pair_tri")) {
+        g->pair_tri = (int)value;
     } else if (!strcmp(name, "fmin_direct")) {
         g->fmin_direct = (int)value;
         g->fmin_valid = false;

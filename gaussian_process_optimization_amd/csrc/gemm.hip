@@ -59,6 +59,7 @@ struct GemmArgs {
     long sC, sA, sB;  // batch strides (elements) applied with blockIdx.y
     const short *tile_list;  // optional explicit (row tile, col tile) order (L2-friendly super-tiles)
     int stagger;             // > 0: odd-slot workgroups start stagger * 1024 cycles late
+    int pair;                // k_end_tri products: a workgroup takes column tiles c1-1-p and c0+p (equal total K)
 };
 
 __device__ __forceinline__ void tile_from_linear(long t, const GemmArgs &a, int &i, int &c) {
@@ -92,7 +93,7 @@ __device__ __forceinline__ void tile_from_linear(long t, const GemmArgs &a, int 
 // 2x2 accumulators per wave, a quarter of the work per workgroup and up to 4 workgroups/CU -- used for the
 // short launches of the factorisation's latency chain and the uneven triangular-K products).  With BT = 64
 // every 128x128 tile of the tile set is computed by four workgroups.
-template <int MODE, int BT, int NWN>
+template <int MODE, int BT, int NWN, bool PAIR = false>
 __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kernel(GemmArgs a) {
     constexpr int NTH = 128 * NWN;         // threads: 2 x NWN waves
     constexpr int MT = BT / 32;            // 16x16 MFMA tiles per wave along m
@@ -114,8 +115,15 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
         wg >>= 2;
     }
 
-    int ti, tc;
-    if (a.tile_list) {
+    int ti, tc, tc2 = -1;
+    if (PAIR) {
+        // balanced triangular-K product: column tiles c1-1-p (longest K) and c0+p (shortest) in one workgroup
+        const int nr = a.r1 - a.r0;
+        const int cp = (int)(wg / nr);
+        ti = a.r0 + (int)(wg % nr);
+        tc = a.c1 - 1 - cp;
+        tc2 = a.c0 + cp;
+    } else if (a.tile_list) {
         ti = a.tile_list[2 * wg];
         tc = a.tile_list[2 * wg + 1];
     } else {
@@ -124,6 +132,7 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
     // the triangular decode goes through a VALU sqrt: tell the compiler the result is wave-uniform
     ti = __builtin_amdgcn_readfirstlane(ti);
     tc = __builtin_amdgcn_readfirstlane(tc);
+    tc2 = __builtin_amdgcn_readfirstlane(tc2);
     const int sr = (BT == 64) ? (sub >> 1) * 64 : 0;  // row / column offset of this workgroup inside the 128-tile
     const int sc = (BT == 64) ? (sub & 1) * 64 : 0;
 
@@ -133,6 +142,9 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
     const int wm = wave / NWN, wn = wave % NWN;
     const int li = lane & 15, lg = lane >> 4;
 
+    const int npass = (PAIR && tc2 != tc) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+    if (PAIR && pass == 1) tc = tc2;
     const long z = blockIdx.y;
     const int kstart = a.k_tri ? ti * GP_TILE : 0;
     const int kend = a.k_end_tri ? (tc - a.b_sub + 1) * GP_TILE : a.K;
@@ -254,6 +266,7 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 buf_store_f64(crs, cbyte + n * 128, (unsigned)(m * 16 + 4 * r) * crow, acc[m][n][r]);
+    }  // pass
 }
 
 void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *A, long lda,
@@ -268,7 +281,16 @@ void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *
     a.sC = o.sC; a.sA = o.sA; a.sB = o.sB;
     a.tile_list = o.tile_list;
     a.stagger = o.stagger;
-    if (o.small) {
+    a.pair = o.pair;
+    if (o.small && o.pair) {
+        // pairs of column tiles: ceil(W/2) workgroup columns per row tile
+        const long np = (long)(ts.r1 - ts.r0) * ((ts.c1 - ts.c0 + 1) / 2);
+        dim3 grid((unsigned)(4 * np), (unsigned)o.batch);
+        if (mode == 0)
+            hipLaunchKernelGGL((gemm_nt_kernel<0, 64, 2, true>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nt_kernel<1, 64, 2, true>), grid, dim3(256), 0, s, a);
+    } else if (o.small) {
         dim3 grid((unsigned)(4 * n), (unsigned)o.batch);
         if (mode == 0)
             hipLaunchKernelGGL((gemm_nt_kernel<0, 64, 2>), grid, dim3(256), 0, s, a);

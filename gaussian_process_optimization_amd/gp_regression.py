@@ -209,10 +209,20 @@ class GPRegression(Parameterized):
         self._h.set_candidates(Xnew)
         return Xnew
 
+    def _empty(self, Xnew, full_cov):
+        """Zero prediction locations: the shapes NumPy gives the reference (posterior.py:273-302 on a (0, D) array)."""
+        Xnew = np.asarray(Xnew, dtype=float)
+        if Xnew.ndim == 2 and Xnew.shape[0] == 0:
+            return np.empty((0, self.output_dim)), (np.empty((0, 0)) if full_cov else np.empty((0, 1)))
+        return None
+
     def _raw_predict(self, Xnew, full_cov=False, kern=None):
         """gp.py:279-295 -> PosteriorExact._raw_predict (posterior.py:273-302)."""
         if kern is not None and kern is not self.kern:
             raise NotImplementedError("prediction with a foreign kernel is outside the accelerated path")
+        e = self._empty(Xnew, full_cov)
+        if e is not None:
+            return e
         self._stage(Xnew)
         if full_cov:
             return self._h.predict_full_cov(include_noise=False)
@@ -222,6 +232,9 @@ class GPRegression(Parameterized):
         """gp.py:297-354."""
         if kern is not None and kern is not self.kern:
             raise NotImplementedError("prediction with a foreign kernel is outside the accelerated path")
+        e = self._empty(Xnew, full_cov)
+        if e is not None:
+            return e
         self._stage(Xnew)
         if full_cov:
             mean, var = self._h.predict_full_cov(include_noise=include_likelihood)
@@ -241,6 +254,9 @@ class GPRegression(Parameterized):
 
     def predictive_gradients(self, Xnew, kern=None):
         """gp.py:407-454: (dmu_dX [M, D, P], dv_dX [M, D])."""
+        Xn = np.asarray(Xnew, dtype=float)
+        if Xn.ndim == 2 and Xn.shape[0] == 0:
+            return np.empty((0, self.input_dim, self.output_dim)), np.empty((0, self.input_dim))
         self._stage(Xnew)
         return self._h.predict_grad()
 

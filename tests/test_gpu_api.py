@@ -406,3 +406,22 @@ def test_gower_mixed_variable_kernel():
     gm.model.optimize(max_iters=15)
     assert gm.model.log_likelihood() >= l0 - 1e-6
     gm.model.close()
+
+
+def test_empty_candidate_set_and_shape_errors():
+    """Zero prediction rows give the empty arrays NumPy gives the reference; wrong column counts raise."""
+    rng = np.random.RandomState(0)
+    X = rng.rand(40, 3); Y = rng.randn(40, 1)
+    m = gpo.models.GPRegression(X, Y, kernel=gpo.kern.RBF(3), noise_var=0.1)
+    mu, var = m.predict(np.empty((0, 3)))
+    assert mu.shape == (0, 1) and var.shape == (0, 1)
+    mu, cov = m.predict(np.empty((0, 3)), full_cov=True)
+    assert mu.shape == (0, 1) and cov.shape == (0, 0)
+    dm, dv = m.predictive_gradients(np.empty((0, 3)))
+    assert dm.shape == (0, 3, 1) and dv.shape == (0, 3)
+    with pytest.raises(ValueError):
+        m.predict(rng.rand(5, 2))
+    # a single 1-D location is promoted to one row (gpmodel.py:96-97)
+    mu, var = m.predict(rng.rand(3))
+    assert mu.shape == (1, 1) and var.shape == (1, 1)
+    m.close()

@@ -127,7 +127,9 @@ struct gp_ctx {
     int panel_tiles_tail = 0, tail_rows = 0;  // narrower factorisation panels once fewer than tail_rows row tiles remain
     int waves8 = 1;
     int stagger = 3;  // see gemm.hip: odd-slot workgroups start 3 * 1024 cycles late (+1.5 % measured)
-    int pipe_start_pct = 0;   // gp_fit_predict: candidate stages start once this share of the panels is factored
+    int pipe_stages = 3;         // gp_fit_predict: candidate stages that ride behind the factorisation (rest afterwards)
+    int pipe_done = 0;           // ... how many did, in the last factorisation
+    int pipe_start_pct = 40;     // ... released once this share of the panels is factored (the chain sets the pace from there)
     std::vector<int> gemm_K;
     size_t gemm_ev_used = 0;
     long gemm_launches = 0;
@@ -398,6 +400,9 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "profile_min_tiles")) {
         if (value < 0) return fail(GP_ERR_ARG, "profile_min_tiles < 0");
         g->profile_min_tiles = value;
+    } else if (!strcmp(name, "pipe_stages")) {
+        if (value < 1) return fail(GP_ERR_ARG, "pipe_stages < 1");
+        g->pipe_stages = (int)std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "pair_tri")) {
         g->pair_tri = (int)value;
     } else if (!strcmp(name, "fmin_direct")) {
@@ -605,7 +610,10 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     // events: 1 + 2J = chain(J) done, 2 + 2J = bulk(J) done; 1000 + J = invP_J built
     int next_pred = 0;
     const int nJu = (nt + W - 1) / W;
-    const int pred_start = std::min(nJu - 1, nJu * g->pipe_start_pct / 100);
+    // Only the first `pipe_stages` candidate stages ride behind the factorisation (on the CU-masked stream, released
+    // at panel pred_start); the caller runs the rest on the main stream, on every CU, once the factor is complete.
+    const int pstages = pp.on ? std::max(1, std::min(nJu, g->pipe_stages)) : 0;
+    const int pred_start = std::max(0, std::min(nJu - 1, nJu * g->pipe_start_pct / 100));
     // panel boundaries: W tiles while the trailing matrix is tall; `panel_tiles_tail` once fewer than `tail_rows`
     // row tiles remain (the chain sets the pace there and a narrower panel means a shorter look-ahead update
     // between two chains).  The pipelined candidate solve needs the uniform panels its inverses are built on.
@@ -640,14 +648,19 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
         hipEventRecord(eF, sp);
         const int K = (J1 - J0) * GP_TILE;
         if (pp.on) {
-            hipStreamWaitEvent(g->s_inv, eF, 0);
-            build_panel_inv_one(g, g->s_inv, J, W, nt);
-            hipEventRecord(la_event(g, 1000 + J), g->s_inv);
-            // Two concurrent MFMA-bound launches run slower than one after the other (measured 51 vs 63 TFLOP/s:
-            // they evict each other's operand panels from L2), so the candidate stages are held back until the
-            // factorisation turns latency-bound (panel >= pred_start) and only then released, in order.
+            if (J < pstages) {
+                hipStreamWaitEvent(g->s_inv, eF, 0);
+                build_panel_inv_one(g, g->s_inv, J, W, nt);
+                hipEventRecord(la_event(g, 1000 + J), g->s_inv);
+            }
+            // Two concurrent MFMA-bound launches run slower than one after the other (measured 51 vs 63 TFLOP/s), and
+            // the candidate stream is CU-masked like the trailing update (the diagonal-tile workgroup needs an empty
+            // CU), which costs it 1/8 of the chip.  So only the first `pipe_stages` stages ride here, released once
+            // the factorisation turns latency-bound (panel >= pred_start): they fill the CUs the chain leaves idle in
+            // the tail.  The rest run after the join on the main stream, on every CU (fit_impl).  Measured at C3:
+            // 73.4 ms against 77.0 for gp_fit + gp_predict; every stage pipelined: 78.1.
             if (J >= pred_start) {
-                for (; next_pred <= J; ++next_pred) {
+                for (; next_pred <= J && next_pred < pstages; ++next_pred) {
                     const int Q = next_pred, Q0 = Q * W, Q1 = std::min(Q0 + W, nt);
                     const int KQ = (Q1 - Q0) * GP_TILE;
                     hipStreamWaitEvent(g->s_pred, la_event(g, 1 + 2 * J), 0);
@@ -682,6 +695,7 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     hipEventRecord(eb, sb);
     hipStreamWaitEvent(g->s, ep, 0);
     hipStreamWaitEvent(g->s, eb, 0);
+    g->pipe_done = pstages;
     if (pp.on) {
         hipEvent_t eq = la_event(g, 1 + 2 * nJ + 3), ei = la_event(g, 1 + 2 * nJ + 4);
         hipEventRecord(eq, g->s_pred);
@@ -771,14 +785,14 @@ static int ensure_panel_inv(gp_ctx *g) {
 // Row solve  S = T L^-T  for `mt` row tiles of T (row-major, ld = Npad); T is consumed as the running
 // right-hand side.  trapezoid = 1: T is block upper-triangular (row tile r is zero left of column tile r:
 // the identity, for L^-T), so panel J only touches the row tiles above its end.
-static void solve_rows(gp_ctx *g, double *T, double *S, int mt, int trapezoid) {
+static void solve_rows(gp_ctx *g, double *T, double *S, int mt, int trapezoid, int J_from = 0) {
     const long Npad = g->Npad, lda = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
     const int W = g->invp_W;
     const long PB = (long)W * GP_TILE;
     const double *L = g->dA;
     hipStream_t s = g->s;
-    for (int J0 = 0, J = 0; J0 < nt; J0 += W, ++J) {
+    for (int J0 = J_from * W, J = J_from; J0 < nt; J0 += W, ++J) {
         const int J1 = std::min(J0 + W, nt);
         const int Kp = (J1 - J0) * GP_TILE;
         const int rows = trapezoid ? std::min(mt, J1) : mt;
@@ -891,9 +905,19 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         g->nphases = 0;
     }
     g->jitter = jitter;
-    if (pipe) {  // every inverted panel was built by the pipeline
-        g->invp_W = std::min(g->panel_tiles, nt_);
-        g->invp_valid = true;
+    if (pipe) {
+        const int W = std::min(g->panel_tiles, nt_);
+        const int nJ = (nt_ + W - 1) / W;
+        if (g->pipe_done >= nJ) {  // every inverted panel was built by the pipeline
+            g->invp_W = W;
+            g->invp_valid = true;
+        } else {  // the remaining candidate stages on the main stream, every CU
+            int phr = phase_begin(g, "cand_solve_rest", 0.0, 0.0);
+            int rci = ensure_panel_inv(g);
+            if (rci) return rci;
+            solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), 0, g->pipe_done);
+            phase_end(g, phr);
+        }
     }
 
     int ph = phase_begin(g, "alpha_lml", 2.0 * (double)N * N * P, 8.0 * (double)N * N / 2);

@@ -246,11 +246,15 @@ def test_state_errors(h):
     hd.close()
 
 
+@pytest.mark.parametrize("stages,start", [(3, 40), (1, 0), (2, 60), (1 << 20, 0), (1 << 20, 70)])
 @pytest.mark.parametrize("N,M,pt", [(1500, 700, 2), (2048, 300, 4), (1100, 129, 3), (600, 50, 8)])
-def test_fit_predict_pipelined_equals_separate_calls(h, N, M, pt):
-    """gp_fit_predict pipelines the candidate solve behind the factorisation; same arithmetic, same results."""
+def test_fit_predict_pipelined_equals_separate_calls(h, N, M, pt, stages, start):
+    """gp_fit_predict runs the first `pipe_stages` candidate stages behind the factorisation (released at
+    `pipe_start_pct` % of the panels) and the rest after it; same arithmetic, bitwise the same results."""
     X, Y, Xs = O.synthetic_problem(N, 5, M, seed=N)
     h.set_option("panel_tiles", pt)
+    h.set_option("pipe_stages", stages)
+    h.set_option("pipe_start_pct", start)
     h.set_data(X, Y)
     h.set_params(1, 0, 1.2, [0.7], 1e-2)
     h.set_candidates(Xs)
@@ -268,7 +272,9 @@ def test_fit_predict_pipelined_equals_separate_calls(h, N, M, pt):
     gp = O.OracleGP(X, Y, O.Matern52(5, 1.2, 0.7), 1e-2)
     mo, vo = gp.predict(Xs)
     assert relmax(m1, mo) < 1e-6 and np.max(np.abs(v1 - vo) / vo) < 1e-6
-    h.set_option("panel_tiles", 8)
+    h.set_option("panel_tiles", 6)
+    h.set_option("pipe_stages", 3)
+    h.set_option("pipe_start_pct", 40)
 
 
 def test_fit_predict_jitter_and_failure(golden, h):

@@ -71,7 +71,12 @@ class AcquisitionBase(object):
     def _device_stage(self, x):
         gp = self.model.model
         x = np.atleast_2d(np.asarray(x, dtype=float))
-        gp._stage(x)
+        if gp._dirty:
+            # a refit is pending (new data / hyper-parameters): fit and the posterior at x go down as one call
+            gp._stage(x, fit=False)
+            gp._predict_resident(True)   # GPModel.predict: with_noise=True (gpmodel.py:102); kept resident on the device
+        else:
+            gp._stage(x)
         nz = gp.normalizer
         y_mean = float(nz.mean[0]) if nz is not None else 0.0
         y_std = float(nz.std[0]) if nz is not None else 1.0

@@ -159,6 +159,11 @@ class GPRegression(Parameterized):
         """GP.parameters_changed, gp.py:258-271: inference on the device when anything changed."""
         if not self._dirty:
             return
+        self._push_params()
+        self._lml, self._logdet, self._jitter = self._h.fit(self.max_jitter_tries)
+        self._dirty = False
+
+    def _push_params(self):
         k = self.kern
         self._h.set_params(k._kernel_id, k.ARD, float(k.variance), k.lengthscale.values,
                            float(self.likelihood.variance))
@@ -166,8 +171,17 @@ class GPRegression(Parameterized):
             self._h.set_gower(*gower_config(k.space, k.input_dim))
         else:
             self._h.set_gower()
-        self._lml, self._logdet, self._jitter = self._h.fit(self.max_jitter_tries)
-        self._dirty = False
+
+    def _predict_resident(self, include_noise):
+        """Mean / variance at the staged candidates.  When the model has to be (re)fitted first -- new data or new
+        hyper-parameters, the state every BO iteration starts in (core/bo.py:236-254 then acquisitions/base.py:33-39)
+        -- fit and predict go down as ONE call, gp_fit_predict (bitwise the results of the two calls)."""
+        if self._dirty:
+            self._push_params()
+            (self._lml, self._logdet, self._jitter), mean, var = self._h.fit_predict(include_noise, self.max_jitter_tries)
+            self._dirty = False
+            return mean, var
+        return self._h.predict(include_noise=include_noise)
 
     def parameters_changed(self):
         self._dirty = True
@@ -201,11 +215,12 @@ class GPRegression(Parameterized):
         return np.concatenate([np.atleast_1d(np.asarray(x, dtype=float)).reshape(-1) for _, x in g])
 
     # -- prediction ---------------------------------------------------------------------
-    def _stage(self, Xnew):
+    def _stage(self, Xnew, fit=True):
         Xnew = np.asarray(Xnew, dtype=float)
         if Xnew.ndim == 1:
             Xnew = Xnew[None, :]
-        self._ensure_fit()
+        if fit:
+            self._ensure_fit()
         self._h.set_candidates(Xnew)
         return Xnew
 
@@ -223,10 +238,10 @@ class GPRegression(Parameterized):
         e = self._empty(Xnew, full_cov)
         if e is not None:
             return e
-        self._stage(Xnew)
+        self._stage(Xnew, fit=full_cov)
         if full_cov:
             return self._h.predict_full_cov(include_noise=False)
-        return self._h.predict(include_noise=False)
+        return self._predict_resident(False)
 
     def predict(self, Xnew, full_cov=False, Y_metadata=None, kern=None, likelihood=None, include_likelihood=True):
         """gp.py:297-354."""
@@ -235,11 +250,11 @@ class GPRegression(Parameterized):
         e = self._empty(Xnew, full_cov)
         if e is not None:
             return e
-        self._stage(Xnew)
+        self._stage(Xnew, fit=full_cov)
         if full_cov:
             mean, var = self._h.predict_full_cov(include_noise=include_likelihood)
         else:
-            mean, var = self._h.predict(include_noise=include_likelihood)
+            mean, var = self._predict_resident(include_likelihood)
         if self.normalizer is not None:
             mean = self.normalizer.inverse_mean(mean)
             if full_cov and mean.shape[1] > 1:

@@ -425,3 +425,31 @@ def test_empty_candidate_set_and_shape_errors():
     mu, var = m.predict(rng.rand(3))
     assert mu.shape == (1, 1) and var.shape == (1, 1)
     m.close()
+
+
+def test_one_call_fit_predict_path_in_the_host_mirror():
+    """A prediction or an acquisition on a model with a pending refit goes through gp_fit_predict; the numbers are
+    bitwise those of an explicit fit followed by the same prediction."""
+    rng = np.random.RandomState(1)
+    N, D, M = 900, 4, 300
+    X = rng.rand(N, D); Y = np.sin(4 * X.sum(1, keepdims=True)) + 0.05 * rng.randn(N, 1); Xs = rng.rand(M, D)
+    m = gpo.models.GPRegression(X, Y, kernel=gpo.kern.Matern52(D, lengthscale=0.5), noise_var=0.01)
+    m.kern.lengthscale[:] = 0.45            # -> dirty
+    assert m._dirty
+    mu1, v1 = m.predict(Xs)                 # one call
+    names = [p["name"] for p in m._h.phases()]
+    assert any("cholesky+cand_solve" in n for n in names) and not m._dirty
+    m.kern.lengthscale[:] = 0.45
+    m._dirty = True
+    lml = m.log_likelihood()                # explicit fit ...
+    mu2, v2 = m.predict(Xs)                 # ... then predict
+    assert np.array_equal(mu1, mu2) and np.array_equal(v1, v2) and np.isfinite(lml)
+    # acquisition through the device fast path, refit pending
+    gm = gpo.GPModel(exact_feval=False, optimize_restarts=1, max_iters=5, verbose=False)
+    gm.updateModel(X, Y, None, None)
+    acq = gpo.acquisitions.AcquisitionEI(gm, None, None, None, 0.01)
+    a1 = acq.acquisition_function(Xs)
+    gm.model._dirty = True                  # force the pending-refit state with the same hyper-parameters
+    a2 = acq.acquisition_function(Xs)
+    assert np.array_equal(a1, a2)
+    m.close(); gm.model.close()

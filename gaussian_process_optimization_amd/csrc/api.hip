@@ -120,7 +120,8 @@ struct gp_ctx {
     int supertile = 0;
     int small_below = 1400;  // launches with fewer 128-tiles than this use 64x64 workgroup tiles
     int chain_small_below = 400;  // ... the same threshold for the launches of the factorisation's chain stream
-    int pair_tri = 1;        // triangular-K products: pair column tiles c and W-1-c in one workgroup
+    int lauum_panels = 1;    // Ky^-1 product accumulated per k-panel (0: one launch over the whole contraction)
+    int pair_tri = 2;        // triangular-K products: pair column tiles c and W-1-c in one workgroup (1: 64x64 units only)
     int fmin_direct = 0;     // gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha
     int inner_left_rows = 1 << 30;  // panels with at least this many row tiles update their columns left-looking
     int trsm_waves8 = 0;     // in-place panel solves on the 8-wave variant
@@ -239,7 +240,8 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
     if (small_thr > 0 && n < small_thr && !oo.inplace) oo.small = 1;
     // products with an inverted panel: column tile c contracts c+1 K-blocks; pairing c with W-1-c gives every
     // workgroup the same W+1 blocks (one balanced round of workgroups instead of a long and a short one)
-    if (g->pair_tri && oo.small && o.k_end_tri && !ts.tri && !o.tile_list && ts.c1 - ts.c0 >= 2) oo.pair = 1;
+    if (g->pair_tri && (oo.small || (oo.waves8 && g->pair_tri >= 2)) && o.k_end_tri && !ts.tri && !o.tile_list && ts.c1 - ts.c0 >= 2)
+        oo.pair = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // events only around the launches that carry the flops (>= 1024 output tiles): bracketing every one of the
     // ~700 small launches of an iteration stalls the latency chain (34 -> 53 ms per factorisation, measured)
@@ -403,6 +405,9 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "pipe_stages")) {
         if (value < 1) return fail(GP_ERR_ARG, "pipe_stages < 1");
         g->pipe_stages = (int)std::min<int64_t>(value, 1 << 20);
+    } else if (!strcmp(name, "lauum_panels")) {
+        g->lauum_panels = (int)value;
+        g->wi_valid = false;
     } else if (!strcmp(name, "pair_tri")) {
         g->pair_tri = (int)value;
     } else if (!strcmp(name, "fmin_direct")) {
@@ -1397,15 +1402,34 @@ static int ensure_wi(gp_ctx *g) {
     if ((rc = dev_realloc(&g->dWi, &g->capWi, Npad * Npad))) return rc;
     double *T = g->dT;
     hipStream_t s = g->s;
-    int ph = phase_begin(g, "potri", 2.0 * (double)g->N * g->N * g->N / 3.0, 0.0);
+    int ph = phase_begin(g, "potri_solve", (double)g->N * g->N * g->N / 3.0, 0.0);
     launch_set_identity(s, T, Npad, Npad);
     solve_rows(g, T, g->dT2, nt, 1);  // dT2 = L^-T (block upper triangular)
-    {
+    phase_end(g, ph);
+    ph = phase_begin(g, "potri_lauum", (double)g->N * g->N * g->N / 3.0, 0.0);
+    if (g->lauum_panels) {
+        // Ky^-1 = (L^-T)(L^-T)^T accumulated k-panel by k-panel: panel p (W tiles of k) adds to the tiles (i, c), c <= i,
+        // with i below the panel's end.  Every tile of a launch then walks the SAME k range, so the workgroups of an
+        // XCD share their operand panels in L2 like the trailing updates do; as one launch over k = i*128 .. N each
+        // tile streams its own up-to-33 MB row panels at its own offset and the product runs at the fabric's pace
+        // (47 TFLOP/s at N = 32768).  The accumulator holds -Ky^-1 (C -= A B^T is the kernel's update form).
+        HIPCHK(hipMemsetAsync(g->dWi, 0, sizeof(double) * Npad * Npad, s));
+        const int W = g->panel_tiles;
+        for (int k0 = 0; k0 < nt; k0 += W) {
+            const int k1 = std::min(k0 + W, nt);
+            GemmOpt o;
+            o.k_tri = 1;
+            o.k_sub = k0;
+            gemm(g, s, 1, g->dWi, Npad, g->dT2 + (long)k0 * GP_TILE, Npad, g->dT2 + (long)k0 * GP_TILE, Npad, 1,
+                 (k1 - k0) * GP_TILE, TileSet{0, k1, 0, k1, 1}, o);
+        }
+        launch_symmetrize_scale(s, g->dWi, Npad, Npad, -1.0);
+    } else {
         GemmOpt o;
         o.k_tri = 1;
         gemm(g, s, 0, g->dWi, Npad, g->dT2, Npad, g->dT2, Npad, 1, (int)Npad, TileSet{0, nt, 0, nt, 1}, o);
+        launch_symmetrize(s, g->dWi, Npad, Npad);
     }
-    launch_symmetrize(s, g->dWi, Npad, Npad);
     phase_end(g, ph);
     g->wi_valid = true;
     g->predicted = false;  // dT was reused

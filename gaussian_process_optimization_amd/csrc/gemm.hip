@@ -53,7 +53,8 @@ struct GemmArgs {
     int b_mul;
     int K;
     int r0, r1, c0, c1, tri;
-    int k_tri;      // contraction starts at column ti*128 (A is block upper-triangular: lauum-type products)
+    int k_tri;      // contraction starts at column max(0, ti - k_sub)*128 (A is block upper-triangular: lauum-type products)
+    int k_sub;
     int k_end_tri;  // contraction ends after column tile (tc - b_sub): B is block lower-triangular
     int b_sub;      // B row tile = (tc - b_sub) * b_mul
     long sC, sA, sB;  // batch strides (elements) applied with blockIdx.y
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
     for (int pass = 0; pass < npass; ++pass) {
     if (PAIR && pass == 1) tc = tc2;
     const long z = blockIdx.y;
-    const int kstart = a.k_tri ? ti * GP_TILE : 0;
+    const int kstart = a.k_tri ? (ti > a.k_sub ? ti - a.k_sub : 0) * GP_TILE : 0;
     const int kend = a.k_end_tri ? (tc - a.b_sub + 1) * GP_TILE : a.K;
     const double *Ag = a.A + z * a.sA + ((long)ti * GP_TILE + sr) * a.lda + kstart;
     const double *Bg = a.B + z * a.sB + ((long)(tc - a.b_sub) * a.b_mul * GP_TILE + sc) * a.ldb + kstart;
@@ -277,7 +278,7 @@ void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *
     a.C = C; a.ldc = ldc; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
     a.b_mul = b_mul; a.K = K;
     a.r0 = ts.r0; a.r1 = ts.r1; a.c0 = ts.c0; a.c1 = ts.c1; a.tri = ts.tri;
-    a.k_tri = o.k_tri; a.k_end_tri = o.k_end_tri; a.b_sub = o.b_sub;
+    a.k_tri = o.k_tri; a.k_sub = o.k_sub; a.k_end_tri = o.k_end_tri; a.b_sub = o.b_sub;
     a.sC = o.sC; a.sA = o.sA; a.sB = o.sB;
     a.tile_list = o.tile_list;
     a.stagger = o.stagger;
@@ -290,6 +291,13 @@ void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *
             hipLaunchKernelGGL((gemm_nt_kernel<0, 64, 2, true>), grid, dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL((gemm_nt_kernel<1, 64, 2, true>), grid, dim3(256), 0, s, a);
+    } else if (o.waves8 && o.pair) {
+        const long np = (long)(ts.r1 - ts.r0) * ((ts.c1 - ts.c0 + 1) / 2);
+        dim3 grid((unsigned)np, (unsigned)o.batch);
+        if (mode == 0)
+            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 4, true>), grid, dim3(512), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 4, true>), grid, dim3(512), 0, s, a);
     } else if (o.small) {
         dim3 grid((unsigned)(4 * n), (unsigned)o.batch);
         if (mode == 0)

@@ -44,7 +44,8 @@ static inline long tileset_count(const TileSet &t) {
 // B rows   at B + (c*b_mul)*128*ldb    (K columns)
 // mode 0: C = A B^T ; mode 1: C -= A B^T
 struct GemmOpt {
-    int k_tri = 0;      // k starts at the output row tile (A block upper-triangular)
+    int k_tri = 0;      // k starts at the output row tile (A block upper-triangular) ...
+    int k_sub = 0;      // ... minus k_sub tiles (the A / B pointers already sit at column tile k_sub)
     int k_end_tri = 0;  // k ends after column tile (tc - b_sub) (B block lower-triangular)
     int b_sub = 0;      // B row tile = (tc - b_sub) * b_mul
     int batch = 1;      // blockIdx.y instances with pointer strides sC, sA, sB (elements)
@@ -110,6 +111,8 @@ void launch_argbest(hipStream_t s, const double *v, long n, int sense, double *b
 #define GP_GRAD_NACC (GP_GRAD_CH + 2)
 void launch_set_identity(hipStream_t s, double *T, long ld, long n);
 void launch_symmetrize(hipStream_t s, double *A, long ld, long n);
+// A = scale * lower(A), mirrored into the upper triangle
+void launch_symmetrize_scale(hipStream_t s, double *A, long ld, long n, double scale);
 void launch_lml_grad(hipStream_t s, const double *X, long N, long Npad, const KernParams &kp, int ard, int d0,
                      const double *alpha, int P, const double *Wi, long ldw, double *partial, double *out);
 void launch_predict_grad(hipStream_t s, const double *Xs, long M, const double *X, long N, const KernParams &kp,

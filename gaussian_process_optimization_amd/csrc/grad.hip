@@ -69,6 +69,29 @@ __global__ void symmetrize_kernel(double *A, long ld, long n) {
         if (gi < n && gj < n && gj > gi) A[gi * ld + gj] = t[tx][r];
     }
 }
+__global__ void symmetrize_scale_kernel(double *A, long ld, long n, double scale) {
+    __shared__ double t[32][33];
+    const int bx = blockIdx.x, by = blockIdx.y;  // by >= bx: source tile (by, bx) in the lower part
+    if (bx > by) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const long gi = (long)by * 32 + r, gj = (long)bx * 32 + tx;
+        t[r][tx] = (gi < n && gj < n) ? A[gi * ld + gj] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long gi = (long)by * 32 + r, gj = (long)bx * 32 + tx;
+        if (gi < n && gj < n && gj <= gi) A[gi * ld + gj] = scale * t[r][tx];
+    }
+    for (int r = ty; r < 32; r += 8) {
+        const long gi = (long)bx * 32 + r, gj = (long)by * 32 + tx;
+        if (gi < n && gj < n && gj > gi) A[gi * ld + gj] = scale * t[tx][r];
+    }
+}
+void launch_symmetrize_scale(hipStream_t s, double *A, long ld, long n, double scale) {
+    const unsigned nb = (unsigned)((n + 31) / 32);
+    hipLaunchKernelGGL(symmetrize_scale_kernel, dim3(nb, nb), dim3(256), 0, s, A, ld, n, scale);
+}
 void launch_symmetrize(hipStream_t s, double *A, long ld, long n) {
     const unsigned nb = (unsigned)((n + 31) / 32);
     hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, s, A, ld, n);

@@ -40,6 +40,8 @@ SIGNATURES = [
     ("gp_get_woodbury_inv", ctypes.c_int, [_vp, c_double_p]),
     ("gp_kernel_matrix", ctypes.c_int, [_vp, c_double_p]),
     ("gp_lml_grad", ctypes.c_int, [_vp, c_double_p, c_double_p, c_double_p]),
+    ("gp_fit_grad", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                   c_double_p]),
     ("gp_set_candidates", ctypes.c_int, [_vp, c_double_p, ctypes.c_int64]),
     ("gp_predict", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p]),
     ("gp_predict_full_cov", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p]),
@@ -191,6 +193,16 @@ class Handle(object):
                                      ctypes.byref(logdet), ctypes.byref(jit), dptr(mean), dptr(var))
         check(self.lib, rc, "gp_fit_predict")
         return (lml.value, logdet.value, jit.value), mean, var
+
+    def fit_grad(self, nls, maxtries=5):
+        """gp_fit + gp_lml_grad as one call: ((lml, logdet, jitter), (dvariance, dlengthscale[nls], dnoise))."""
+        lml, logdet, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        dv, dn = ctypes.c_double(), ctypes.c_double()
+        dl = np.empty(nls)
+        rc = self.lib.gp_fit_grad(self.h, int(maxtries), ctypes.byref(lml), ctypes.byref(logdet), ctypes.byref(jit),
+                                  ctypes.byref(dv), dptr(dl), ctypes.byref(dn))
+        check(self.lib, rc, "gp_fit_grad")
+        return (lml.value, logdet.value, jit.value), (dv.value, dl, dn.value)
 
     def alpha(self):
         out = np.empty((self.N, self.P))

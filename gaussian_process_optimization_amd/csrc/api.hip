@@ -128,6 +128,7 @@ struct gp_ctx {
     int panel_tiles_tail = 0, tail_rows = 0;  // narrower factorisation panels once fewer than tail_rows row tiles remain
     int waves8 = 1;
     int stagger = 3;  // see gemm.hip: odd-slot workgroups start 3 * 1024 cycles late (+1.5 % measured)
+    int pipe_stages_grad = 8, pipe_start_pct_grad = 40;  // the same for gp_fit_grad (stages of the solve for L^-T)
     int pipe_stages = 3;         // gp_fit_predict: candidate stages that ride behind the factorisation (rest afterwards)
     int pipe_done = 0;           // ... how many did, in the last factorisation
     int pipe_start_pct = 40;     // ... released once this share of the panels is factored (the chain sets the pace from there)
@@ -402,6 +403,12 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "profile_min_tiles")) {
         if (value < 0) return fail(GP_ERR_ARG, "profile_min_tiles < 0");
         g->profile_min_tiles = value;
+    } else if (!strcmp(name, "pipe_stages_grad")) {
+        if (value < 1) return fail(GP_ERR_ARG, "pipe_stages_grad < 1");
+        g->pipe_stages_grad = (int)std::min<int64_t>(value, 1 << 20);
+    } else if (!strcmp(name, "pipe_start_pct_grad")) {
+        if (value < 0 || value > 100) return fail(GP_ERR_ARG, "pipe_start_pct_grad out of range");
+        g->pipe_start_pct_grad = (int)value;
     } else if (!strcmp(name, "pipe_stages")) {
         if (value < 1) return fail(GP_ERR_ARG, "pipe_stages < 1");
         g->pipe_stages = (int)std::min<int64_t>(value, 1 << 20);
@@ -573,6 +580,8 @@ struct PredPipe {
     bool on = false;
     int mt = 0;          // candidate row tiles
     double *T = nullptr, *S = nullptr;
+    bool trapezoid = false;  // T is block upper-triangular (the identity: the solve for L^-T), row tiles above the panel's end only
+    int stages = 0, start_pct = 0;
 };
 
 static void build_panel_inv_one(gp_ctx *g, hipStream_t s, int J, int W, int nt) {
@@ -617,8 +626,8 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     const int nJu = (nt + W - 1) / W;
     // Only the first `pipe_stages` candidate stages ride behind the factorisation (on the CU-masked stream, released
     // at panel pred_start); the caller runs the rest on the main stream, on every CU, once the factor is complete.
-    const int pstages = pp.on ? std::max(1, std::min(nJu, g->pipe_stages)) : 0;
-    const int pred_start = std::max(0, std::min(nJu - 1, nJu * g->pipe_start_pct / 100));
+    const int pstages = pp.on ? std::max(1, std::min(nJu, pp.stages)) : 0;
+    const int pred_start = std::max(0, std::min(nJu - 1, nJu * pp.start_pct / 100));
     // panel boundaries: W tiles while the trailing matrix is tall; `panel_tiles_tail` once fewer than `tail_rows`
     // row tiles remain (the chain sets the pace there and a narrower panel means a shorter look-ahead update
     // between two chains).  The pipelined candidate solve needs the uniform panels its inverses are built on.
@@ -668,16 +677,17 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
                 for (; next_pred <= J && next_pred < pstages; ++next_pred) {
                     const int Q = next_pred, Q0 = Q * W, Q1 = std::min(Q0 + W, nt);
                     const int KQ = (Q1 - Q0) * GP_TILE;
+                    const int prow = pp.trapezoid ? std::min(pp.mt, Q1) : pp.mt;
                     hipStreamWaitEvent(g->s_pred, la_event(g, 1 + 2 * J), 0);
                     hipStreamWaitEvent(g->s_pred, la_event(g, 1000 + Q), 0);
                     GemmOpt o;
                     o.k_end_tri = 1;
                     o.b_sub = Q0;
                     gemm(g, g->s_pred, 0, pp.S, g->Npad, pp.T + (long)Q0 * GP_TILE, g->Npad, g->dInvP + (long)Q * PB * PB,
-                         PB, 1, KQ, TileSet{0, pp.mt, Q0, Q1, 0}, o);
+                         PB, 1, KQ, TileSet{0, prow, Q0, Q1, 0}, o);
                     if (Q1 < nt)
                         gemm(g, g->s_pred, 1, pp.T, g->Npad, pp.S + (long)Q0 * GP_TILE, g->Npad, A + (long)Q0 * GP_TILE, lda,
-                             1, KQ, TileSet{0, pp.mt, Q1, nt, 0});
+                             1, KQ, TileSet{0, prow, Q1, nt, 0});
                 }
             }
         }
@@ -831,6 +841,7 @@ __global__ void dot_ay_kernel(const double *alpha, long lda_, const double *Y, l
 }
 
 static int ensure_out(gp_ctx *g);
+static int wi_lauum(gp_ctx *g);
 
 // Shared body of gp_fit and gp_fit_predict.  pipe != 0: the candidate solve of the resident candidates is
 // pipelined behind the factorisation (PredPipe above) and the posterior reductions are appended.
@@ -839,22 +850,27 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     const long N = g->N, Npad = g->Npad, lda = g->Npad;
     const int P = g->P;
     const int nt_ = (int)(Npad / GP_TILE);
-    const long mcpad = pipe ? round_up(g->M, GP_TILE) : 0;
+    // pipe 1: candidate solve of the resident candidates; pipe 2: the solve of the identity (L^-T, for Ky^-1)
+    const long mcpad = pipe == 1 ? round_up(g->M, GP_TILE) : (pipe == 2 ? Npad : 0);
     PredPipe pp;
     if (pipe) {
         int rc;
         const int W = std::min(g->panel_tiles, nt_);
         const long PB = (long)W * GP_TILE;
         const int nJ = (nt_ + W - 1) / W;
-        if ((rc = ensure_out(g))) return rc;
+        if (pipe == 1 && (rc = ensure_out(g))) return rc;
         if ((rc = dev_realloc(&g->dT, &g->capT, mcpad * Npad))) return rc;
         if ((rc = dev_realloc(&g->dT2, &g->capT2, mcpad * Npad))) return rc;
+        if (pipe == 2 && (rc = dev_realloc(&g->dWi, &g->capWi, Npad * Npad))) return rc;
         if ((rc = dev_realloc(&g->dInvP, &g->capInvP, (long)nJ * PB * PB))) return rc;
         if ((rc = dev_realloc(&g->dInvPw, &g->capInvPw, (long)nJ * PB * PB))) return rc;
         pp.on = true;
         pp.mt = (int)(mcpad / GP_TILE);
         pp.T = g->dT;
         pp.S = g->dT2;
+        pp.trapezoid = (pipe == 2);
+        pp.stages = pipe == 2 ? g->pipe_stages_grad : g->pipe_stages;
+        pp.start_pct = pipe == 2 ? g->pipe_start_pct_grad : g->pipe_start_pct;
     }
     const double diag_add = g->noise + 1e-8;  // exact_gaussian_inference.py:56
     const double diag0 = (g->kp.gower ? std::pow(g->kp.variance, g->D) : g->kp.variance) + diag_add;
@@ -876,11 +892,16 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         launch_set_rhs(g->s, g->dA, lda, g->dY, N, Npad, P);
         phase_end(g, ph);
         HIPCHK(hipMemsetAsync(g->dInfo, 0, sizeof(int) * 4, g->s));
-        if (pipe) {
+        if (pipe == 1) {
             ph = phase_begin(g, "cross_k", 0.0, 8.0 * (double)(N + g->M) * g->D + 8.0 * (double)N * g->M);
             launch_cross_k(g->s, g->dT, Npad, g->dXs, g->M, mcpad, g->dX, N, Npad, g->kp);
             phase_end(g, ph);
             ph = phase_begin(g, "cholesky+cand_solve", (double)N * N * N / 3.0 + (double)N * N * g->M, 0.0);
+            int rcf = factor_lookahead(g, pp);
+            if (rcf) return rcf;
+        } else if (pipe == 2) {
+            ph = phase_begin(g, "cholesky+potri_stages", (double)N * N * N / 3.0, 0.0);
+            launch_set_identity(g->s, g->dT, Npad, Npad);
             int rcf = factor_lookahead(g, pp);
             if (rcf) return rcf;
         } else {
@@ -916,12 +937,17 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         if (g->pipe_done >= nJ) {  // every inverted panel was built by the pipeline
             g->invp_W = W;
             g->invp_valid = true;
-        } else {  // the remaining candidate stages on the main stream, every CU
-            int phr = phase_begin(g, "cand_solve_rest", 0.0, 0.0);
+        } else {  // the remaining stages on the main stream, every CU
+            int phr = phase_begin(g, pipe == 2 ? "potri_solve_rest" : "cand_solve_rest", 0.0, 0.0);
             int rci = ensure_panel_inv(g);
             if (rci) return rci;
-            solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), 0, g->pipe_done);
+            solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), pipe == 2 ? 1 : 0, g->pipe_done);
             phase_end(g, phr);
+        }
+        if (pipe == 2) {
+            int rcl = wi_lauum(g);
+            if (rcl) return rcl;
+            g->wi_valid = true;
         }
     }
 
@@ -934,7 +960,7 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     launch_trsv_backward(g->s, g->dA, lda, g->dInvP, g->invp_W, Npad, g->dA + Npad * lda, lda, P, g->dAlpha, g->dW);
     hipLaunchKernelGGL(dot_ay_kernel, dim3(P), dim3(1024), 0, g->s, g->dAlpha, Npad, g->dY, N, P, g->dScal + 8);
     phase_end(g, ph);
-    if (pipe) {
+    if (pipe == 1) {
         ph = phase_begin(g, "reduce", 0.0, 8.0 * (double)N * g->M);
         launch_predict_reduce(g->s, g->dT2, Npad, g->M, N, g->dA + Npad * Npad, Npad, P, g->kp.variance,
                               include_noise ? g->noise : 0.0, g->dMean, g->dVar);
@@ -949,7 +975,7 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     const double log_2_pi = std::log(2.0 * M_PI);
     g->lml = 0.5 * (-(double)N * P * log_2_pi - P * g->logdet - fit);  // exact_gaussian_inference.py:62
     g->fitted = true;
-    if (pipe) {
+    if (pipe == 1) {
         g->predicted = true;
         g->predicted_noise = include_noise ? 1 : 0;
     }
@@ -1390,22 +1416,12 @@ int gp_comm_bcast_fit(gp_t *g, int root) {
 // Ky^-1 = W W^T with the contraction of tile row a starting at column a*128: another N^3/3.
 // Reference: pdinv / dpotri (GPy/GPy/util/linalg.py:127-145,193-214), Posterior.woodbury_inv
 // (posterior.py:176-196).
-static int ensure_wi(gp_ctx *g) {
-    if (g->wi_valid) return 0;
-    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
-    const long Npad = g->Npad, lda = g->Npad;
+// Ky^-1 from dT2 = L^-T (block upper triangular) into dWi
+static int wi_lauum(gp_ctx *g) {
+    const long Npad = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
-    int rc;
-    if ((rc = ensure_panel_inv(g))) return rc;
-    if ((rc = dev_realloc(&g->dT, &g->capT, Npad * Npad))) return rc;
-    if ((rc = dev_realloc(&g->dT2, &g->capT2, Npad * Npad))) return rc;
-    if ((rc = dev_realloc(&g->dWi, &g->capWi, Npad * Npad))) return rc;
-    double *T = g->dT;
     hipStream_t s = g->s;
-    int ph = phase_begin(g, "potri_solve", (double)g->N * g->N * g->N / 3.0, 0.0);
-    launch_set_identity(s, T, Npad, Npad);
-    solve_rows(g, T, g->dT2, nt, 1);  // dT2 = L^-T (block upper triangular)
-    phase_end(g, ph);
+    int ph;
     ph = phase_begin(g, "potri_lauum", (double)g->N * g->N * g->N / 3.0, 0.0);
     if (g->lauum_panels) {
         // Ky^-1 = (L^-T)(L^-T)^T accumulated k-panel by k-panel: panel p (W tiles of k) adds to the tiles (i, c), c <= i,
@@ -1431,6 +1447,26 @@ static int ensure_wi(gp_ctx *g) {
         launch_symmetrize(s, g->dWi, Npad, Npad);
     }
     phase_end(g, ph);
+    return 0;
+}
+
+static int ensure_wi(gp_ctx *g) {
+    if (g->wi_valid) return 0;
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    const long Npad = g->Npad, lda = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    int rc;
+    if ((rc = ensure_panel_inv(g))) return rc;
+    if ((rc = dev_realloc(&g->dT, &g->capT, Npad * Npad))) return rc;
+    if ((rc = dev_realloc(&g->dT2, &g->capT2, Npad * Npad))) return rc;
+    if ((rc = dev_realloc(&g->dWi, &g->capWi, Npad * Npad))) return rc;
+    double *T = g->dT;
+    hipStream_t s = g->s;
+    int ph = phase_begin(g, "potri_solve", (double)g->N * g->N * g->N / 3.0, 0.0);
+    launch_set_identity(s, T, Npad, Npad);
+    solve_rows(g, T, g->dT2, nt, 1);  // dT2 = L^-T (block upper triangular)
+    phase_end(g, ph);
+    if ((rc = wi_lauum(g))) return rc;
     g->wi_valid = true;
     g->predicted = false;  // dT was reused
     return 0;
@@ -1447,7 +1483,7 @@ int gp_get_woodbury_inv(gp_t *g, double *Wi) {
     return 0;
 }
 
-int gp_lml_grad(gp_t *g, double *dvariance, double *dlengthscale, double *dnoise) {
+static int lml_grad_impl(gp_ctx *g, double *dvariance, double *dlengthscale, double *dnoise, bool reset_phases) {
     if (!g || !dvariance || !dlengthscale || !dnoise) return fail(GP_ERR_ARG, "null argument");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
@@ -1455,7 +1491,7 @@ int gp_lml_grad(gp_t *g, double *dvariance, double *dlengthscale, double *dnoise
                                                "Gower K with Euclidean dK/dr, stationary.py:218-238)");
     HIPCHK(hipSetDevice(g->device));
     int rc;
-    g->nphases = 0;
+    if (reset_phases) g->nphases = 0;
     if ((rc = ensure_wi(g))) return rc;
     const long Npad = g->Npad;
     const int nt = (int)(Npad / GP_TILE), D = g->D;
@@ -1485,6 +1521,31 @@ int gp_lml_grad(gp_t *g, double *dvariance, double *dlengthscale, double *dnoise
         dlengthscale[0] = -host[2] / g->kp.ls[0];  // -sum(dL_dr * r) / l, stationary.py:237-238
     }
     return 0;
+}
+
+int gp_lml_grad(gp_t *g, double *dvariance, double *dlengthscale, double *dnoise) {
+    return lml_grad_impl(g, dvariance, dlengthscale, dnoise, true);
+}
+
+// gp_fit + gp_lml_grad as ONE call (what every L-BFGS evaluation of the hyper-parameter loop asks for:
+// Model.objective_function + objective_function_gradients, core/model.py:96-127).  The first stages of the solve for
+// L^-T ride behind the factorisation's latency-bound tail, like the candidate stages of gp_fit_predict.
+int gp_fit_grad(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_used, double *dvariance,
+                double *dlengthscale, double *dnoise) {
+    if (!g || !dvariance || !dlengthscale || !dnoise) return fail(GP_ERR_ARG, "null argument");
+    if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit_grad");
+    if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
+    if (g->kp.gower) return fail(GP_ERR_STATE, "hyper-gradients of the Gower kernel are not replicated (the fork mixes "
+                                               "Gower K with Euclidean dK/dr, stationary.py:218-238)");
+    HIPCHK(hipSetDevice(g->device));
+    const int nt = (int)(g->Npad / GP_TILE);
+    const bool can_pipe = g->lookahead && nt > g->panel_tiles;
+    int rc;
+    if ((rc = fit_impl(g, maxtries, can_pipe ? 2 : 0, 0))) return rc;
+    if (lml) *lml = g->lml;
+    if (logdet) *logdet = g->logdet;
+    if (jitter_used) *jitter_used = g->jitter;
+    return lml_grad_impl(g, dvariance, dlengthscale, dnoise, false);
 }
 
 // ---- second candidate-sized buffer (beta = K(Xs,X) Ky^-1, or the full covariance) -----------------

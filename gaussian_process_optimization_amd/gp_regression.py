@@ -197,9 +197,16 @@ class GPRegression(Parameterized):
         return -float(self.log_likelihood())
 
     def _log_likelihood_gradients_natural(self):
-        self._ensure_fit()
         nls = self.kern.lengthscale.size
-        dv, dl, dn = self._h.lml_grad(nls)
+        if self._dirty and not self._uses_gower():
+            # objective and gradients of a new parameter vector (every L-BFGS evaluation, core/model.py:96-127):
+            # fit and the Ky^-1 solve go down as ONE call, gp_fit_grad (bitwise the results of the two calls)
+            self._push_params()
+            (self._lml, self._logdet, self._jitter), (dv, dl, dn) = self._h.fit_grad(nls, self.max_jitter_tries)
+            self._dirty = False
+        else:
+            self._ensure_fit()
+            dv, dl, dn = self._h.lml_grad(nls)
         self.kern.variance.gradient = np.atleast_1d(dv)
         self.kern.lengthscale.gradient = dl
         self.likelihood.variance.gradient = np.atleast_1d(dn)
@@ -301,8 +308,11 @@ class GPRegression(Parameterized):
     def _obj_grad(self, x):
         try:
             self.optimizer_array = x
+            if not self._uses_gower():
+                g = self.objective_function_gradients()   # gp_fit_grad: leaves the LML of this x behind
+                return self.objective_function(), g
             f = self.objective_function()
-            if self._uses_gower():
+            if True:  # Gower kernel
                 # the fork pairs the Gower K with Euclidean gradient formulas (stationary.py:218-238), which are not
                 # gradients of this objective; forward differences of the device LML are used instead
                 g = np.empty_like(x)
@@ -313,7 +323,6 @@ class GPRegression(Parameterized):
                     g[i] = (self.objective_function() - f) / 1e-6
                 self.optimizer_array = x
                 return f, g
-            g = self.objective_function_gradients()
         except np.linalg.LinAlgError:
             return 1e10, np.zeros_like(x)  # paramz Model._objective_grads: failed evaluations are walls
         return f, g

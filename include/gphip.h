@@ -95,6 +95,13 @@ int gp_kernel_matrix(gp_t *gp, double *K);
  * Natural-space gradients of the LML; the Logexp chain rule stays on the host. Requires gp_fit. */
 int gp_lml_grad(gp_t *gp, double *dvariance, double *dlengthscale, double *dnoise);
 
+/* gp_fit + gp_lml_grad as ONE call -- what every L-BFGS evaluation of the hyper-parameter loop asks for
+ * (Model.objective_function + objective_function_gradients, GPy/GPy/core/model.py:96-127; GPyOpt
+ * models/gpmodel.py:88-93).  The first "pipe_stages_grad" stages of the solve for L^-T (dpotri, linalg.py:127-145)
+ * ride behind the factorisation's latency-bound tail.  Same results as the two calls in sequence. */
+int gp_fit_grad(gp_t *gp, int maxtries, double *lml, double *logdet, double *jitter_used, double *dvariance,
+                double *dlengthscale, double *dnoise);
+
 /* ---- predict -----------------------------------------------------------
  * Candidates Xs[M,D] are made resident once; the calls below then run on them. */
 int gp_set_candidates(gp_t *gp, const double *Xs, int64_t M);
@@ -194,6 +201,9 @@ int gp_synchronize(gp_t *gp);
  *   "waves8", "stagger", "trsm_waves8", "supertile"   GEMM launch shape
  *   "pipe_stages", "pipe_start_pct"   gp_fit_predict: how many candidate stages ride behind the factorisation (3) and
  *                        after which share of its panels they are released (40)
+ *   "pipe_stages_grad", "pipe_start_pct_grad"   the same for gp_fit_grad (8, 40)
+ *   "lauum_panels"       Ky^-1 product accumulated per k-panel (default 1)
+ *   "pair_tri"           triangular-K products: column tiles paired for equal contraction length (default 2)
  *   "fmin_direct"        gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha (default 0)
  *   "profile_min_tiles"  see gp_profile
  * The number of CUs kept free of the trailing update for the look-ahead chain is fixed per process

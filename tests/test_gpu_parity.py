@@ -310,3 +310,40 @@ def test_fmin_identity_equals_direct_product(h, noise):
         h.set_option("fmin_direct", 0)
     assert abs(f_id - f_dir) <= 1e-9 * max(1.0, abs(f_dir))
     assert abs(f_id - f0) <= 1e-6 * max(1.0, abs(f0))
+
+
+@pytest.mark.parametrize("stages,start", [(8, 40), (1, 0), (3, 70), (1 << 20, 0)])
+@pytest.mark.parametrize("N,D,pt,ard", [(1500, 3, 2, True), (2048, 5, 4, False), (1100, 2, 3, True), (300, 4, 6, True)])
+def test_fit_grad_equals_separate_calls(h, N, D, pt, ard, stages, start):
+    """gp_fit_grad = gp_fit + gp_lml_grad with the first stages of the solve for L^-T behind the factorisation;
+    bitwise the same LML and gradients, and the gradients match the oracle (N = 300: the unpipelined fallback)."""
+    rng = np.random.default_rng(N + D)
+    X = rng.uniform(0, 1, (N, D))
+    Y = np.sin(3 * X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
+    ls = rng.uniform(0.4, 0.9, D) if ard else np.array([0.6])
+    h.set_option("panel_tiles", pt)
+    h.set_option("pipe_stages_grad", stages)
+    h.set_option("pipe_start_pct_grad", start)
+    try:
+        h.set_data(X, Y)
+        h.set_params(1, ard, 1.3, ls, 0.02)
+        f0 = h.fit()
+        g0 = h.lml_grad(ls.size)
+        Wi0 = h.woodbury_inv()
+        f1, g1 = h.fit_grad(ls.size)
+        assert f1 == f0
+        assert g1[0] == g0[0] and np.array_equal(g1[1], g0[1]) and g1[2] == g0[2]
+        assert np.array_equal(Wi0, h.woodbury_inv())
+        gp = O.OracleGP(X, Y, O.make_kernel("Mat52", D, 1.3, ls, ARD=ard), 0.02)
+        r = gp.gradients()
+        sc = max(1.0, abs(r[0]), np.max(np.abs(r[1])), abs(r[2]))
+        assert abs(g1[0] - r[0]) < 1e-6 * sc and np.max(np.abs(g1[1] - r[1])) < 1e-6 * sc and abs(g1[2] - r[2]) < 1e-6 * sc
+        # a following prediction sees the fitted state
+        h.set_candidates(X[:7])
+        mu, var = h.predict(True)
+        m0, v0 = gp.predict(X[:7])
+        assert relmax(mu, m0) < 1e-6 and np.max(np.abs(var - v0) / v0) < 1e-6
+    finally:
+        h.set_option("panel_tiles", 6)
+        h.set_option("pipe_stages_grad", 8)
+        h.set_option("pipe_start_pct_grad", 40)

@@ -125,6 +125,7 @@ struct gp_ctx {
     int fmin_direct = 0;     // gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha
     int inner_left_rows = 1 << 30;  // panels with at least this many row tiles update their columns left-looking
     int trsm_waves8 = 0;     // in-place panel solves on the 8-wave variant
+    int trsm_rows64 = 32;    // in-place panel solves as 64- or 32-row strips of the tile (2 or 4 workgroups per tile)
     int panel_tiles_tail = 0, tail_rows = 0;  // narrower factorisation panels once fewer than tail_rows row tiles remain
     int waves8 = 1;
     int stagger = 3;  // see gemm.hip: odd-slot workgroups start 3 * 1024 cycles late (+1.5 % measured)
@@ -236,6 +237,8 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
     if (n >= 1024 && g->waves8) oo.waves8 = 1;  // 4 waves/SIMD: +2 % on the long launches (measured)
     // in-place panel solves are at most one workgroup per CU: eight waves hide the single tile's LDS/barrier latency
     if (oo.inplace && g->trsm_waves8 && n <= 512) oo.waves8 = 1;
+    // ... or split each tile into two 64-row strips (a strip reads only its own rows of A: still safe in place)
+    if (oo.inplace && g->trsm_rows64 && !oo.waves8) oo.rows64 = g->trsm_rows64;  // 1 / 64: two strips, 32: four
     // short launches (the factorisation's latency chain, the uneven triangular-K products) run as 64x64 work units
     const int small_thr = (s == g->s_panel) ? g->chain_small_below : g->small_below;
     if (small_thr > 0 && n < small_thr && !oo.inplace) oo.small = 1;
@@ -440,6 +443,8 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->tail_rows = (int)value;
     } else if (!strcmp(name, "inner_left_rows")) {
         g->inner_left_rows = (int)value;
+    } else if (!strcmp(name, "trsm_rows64")) {
+        g->trsm_rows64 = (int)value;
     } else if (!strcmp(name, "trsm_waves8")) {
         g->trsm_waves8 = (int)value;
     } else if (!strcmp(name, "mc_max")) {

@@ -94,16 +94,21 @@ __device__ __forceinline__ void tile_from_linear(long t, const GemmArgs &a, int 
 // 2x2 accumulators per wave, a quarter of the work per workgroup and up to 4 workgroups/CU -- used for the
 // short launches of the factorisation's latency chain and the uneven triangular-K products).  With BT = 64
 // every 128x128 tile of the tile set is computed by four workgroups.
-template <int MODE, int BT, int NWN, bool PAIR = false>
-__global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kernel(GemmArgs a) {
+// BM = 64 with BT = 128 (ROWS variant): the workgroup computes a 64-row strip of all 128 columns of the tile -- two
+// workgroups per tile, each reading only its own rows of A, so an IN-PLACE product (C aliases A: the panel solve)
+// can be split over two CUs.
+template <int MODE, int BT, int NWN, bool PAIR = false, int BM = BT>
+__global__ __launch_bounds__(128 * NWN, (BT == 128 ? (BM < BT ? 2 : NWN) : 4)) void gemm_nt_kernel(GemmArgs a) {
     constexpr int NTH = 128 * NWN;         // threads: 2 x NWN waves
-    constexpr int MT = BT / 32;            // 16x16 MFMA tiles per wave along m
+    constexpr int MT = BM / 32;            // 16x16 MFMA tiles per wave along m
     constexpr int NT = BT / NWN / 16;      // ... and along n
-    constexpr int WT = BT / 2;             // wave tile rows
+    constexpr int WT = BM / 2;             // wave tile rows
     constexpr int WTN = BT / NWN;          // wave tile columns
-    constexpr int LQ = BT * 8 / NTH;       // 16-byte staging loads per thread and operand
+    constexpr int LQA = BM * 8 / NTH;      // 16-byte staging loads per thread: A rows ...
+    constexpr int LQ = BT * 8 / NTH;       // ... and B rows
     constexpr int LR = NTH / 8;            // rows covered by one staging load of the workgroup
-    __shared__ __attribute__((aligned(16))) double smem[2 * 2 * BT * LSTR];  // [buf][A|B][BT][18]
+    constexpr int SBUF = (BM + BT) * LSTR; // doubles per stage buffer: [A: BM x 18][B: BT x 18]
+    __shared__ __attribute__((aligned(16))) double smem[2 * SBUF];
 
     // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
     // run of the tile list so that neighbouring tiles (same A row panel) hit the same L2.
@@ -114,6 +119,9 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
     if (BT == 64) {
         sub = (int)(wg & 3);
         wg >>= 2;
+    } else if (BM < BT) {
+        sub = (int)(wg % (BT / BM));
+        wg /= (BT / BM);
     }
 
     int ti, tc, tc2 = -1;
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
     ti = __builtin_amdgcn_readfirstlane(ti);
     tc = __builtin_amdgcn_readfirstlane(tc);
     tc2 = __builtin_amdgcn_readfirstlane(tc2);
-    const int sr = (BT == 64) ? (sub >> 1) * 64 : 0;  // row / column offset of this workgroup inside the 128-tile
+    const int sr = (BT == 64) ? (sub >> 1) * 64 : (BM < BT ? sub * BM : 0);  // row / column offset inside the 128-tile
     const int sc = (BT == 64) ? (sub & 1) * 64 : 0;
 
     const int tid = threadIdx.x;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
             for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
     }
 
-    double2_t ra[LQ], rb[LQ];
+    double2_t ra[LQA], rb[LQ];
     const int nk = (kend - kstart) / BK;
 
     // Two workgroups share a CU (one wave of each per SIMD) and start together, so they would reach their
@@ -201,22 +209,20 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
     }
 
 #pragma unroll
-    for (int q = 0; q < LQ; ++q) {
-        ra[q] = *(const double2_t *)(ap + q * a32);
-        rb[q] = *(const double2_t *)(bp + q * b32);
-    }
-    {
-        double *As = smem, *Bs = smem + BT * LSTR;
+    for (int q = 0; q < LQA; ++q) ra[q] = *(const double2_t *)(ap + q * a32);
 #pragma unroll
-        for (int q = 0; q < LQ; ++q) {
-            *(double2_t *)(As + soff + q * LR * LSTR) = ra[q];
-            *(double2_t *)(Bs + soff + q * LR * LSTR) = rb[q];
-        }
+    for (int q = 0; q < LQ; ++q) rb[q] = *(const double2_t *)(bp + q * b32);
+    {
+        double *As = smem, *Bs = smem + BM * LSTR;
+#pragma unroll
+        for (int q = 0; q < LQA; ++q) *(double2_t *)(As + soff + q * LR * LSTR) = ra[q];
+#pragma unroll
+        for (int q = 0; q < LQ; ++q) *(double2_t *)(Bs + soff + q * LR * LSTR) = rb[q];
     }
     __syncthreads();
 
     const int aoff = (wm * WT + li) * LSTR + lg * 4;
-    const int boff = BT * LSTR + (wn * WTN + li) * LSTR + lg * 4;
+    const int boff = BM * LSTR + (wn * WTN + li) * LSTR + lg * 4;
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -225,13 +231,12 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
             ap += BK;
             bp += BK;
 #pragma unroll
-            for (int q = 0; q < LQ; ++q) {
-                ra[q] = *(const double2_t *)(ap + q * a32);
-                rb[q] = *(const double2_t *)(bp + q * b32);
-            }
+            for (int q = 0; q < LQA; ++q) ra[q] = *(const double2_t *)(ap + q * a32);
+#pragma unroll
+            for (int q = 0; q < LQ; ++q) rb[q] = *(const double2_t *)(bp + q * b32);
         }
-        const double *as = smem + buf * (2 * BT * LSTR) + aoff;
-        const double *bs = smem + buf * (2 * BT * LSTR) + boff;
+        const double *as = smem + buf * SBUF + aoff;
+        const double *bs = smem + buf * SBUF + boff;
         // Lane group lg owns k = 4lg..4lg+3 of the stage; MFMA step (h,e) contracts k = 4g + 2h + e
         // over the four lane groups g, so two ds_read_b128 per operand row-tile feed four MFMA steps.
 #pragma unroll
@@ -250,12 +255,11 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? NWN : 4)) void gemm_nt_kern
                         acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m][e], bf[n][e], acc[m][n], 0, 0, MODE == 1 ? 1 : 0);
         }
         if (more) {
-            double *As = smem + (buf ^ 1) * (2 * BT * LSTR), *Bs = As + BT * LSTR;
+            double *As = smem + (buf ^ 1) * SBUF, *Bs = As + BM * LSTR;
 #pragma unroll
-            for (int q = 0; q < LQ; ++q) {
-                *(double2_t *)(As + soff + q * LR * LSTR) = ra[q];
-                *(double2_t *)(Bs + soff + q * LR * LSTR) = rb[q];
-            }
+            for (int q = 0; q < LQA; ++q) *(double2_t *)(As + soff + q * LR * LSTR) = ra[q];
+#pragma unroll
+            for (int q = 0; q < LQ; ++q) *(double2_t *)(Bs + soff + q * LR * LSTR) = rb[q];
         }
         __syncthreads();
     }
@@ -291,6 +295,18 @@ void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *
             hipLaunchKernelGGL((gemm_nt_kernel<0, 64, 2, true>), grid, dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL((gemm_nt_kernel<1, 64, 2, true>), grid, dim3(256), 0, s, a);
+    } else if (o.rows64 == 32) {
+        dim3 grid((unsigned)(4 * n), (unsigned)o.batch);
+        if (mode == 0)
+            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 2, false, 32>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 2, false, 32>), grid, dim3(256), 0, s, a);
+    } else if (o.rows64) {
+        dim3 grid((unsigned)(2 * n), (unsigned)o.batch);
+        if (mode == 0)
+            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 2, false, 64>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 2, false, 64>), grid, dim3(256), 0, s, a);
     } else if (o.waves8 && o.pair) {
         const long np = (long)(ts.r1 - ts.r0) * ((ts.c1 - ts.c0 + 1) / 2);
         dim3 grid((unsigned)np, (unsigned)o.batch);

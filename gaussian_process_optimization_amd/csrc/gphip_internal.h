@@ -55,6 +55,7 @@ struct GemmOpt {
     int small = 0;                     // 64x64 workgroup tiles (4 workgroups per 128-tile): latency-bound launches
     int waves8 = 0;                    // 128x128 tile on 8 waves (64x32 per wave, 4 waves/SIMD) instead of 4
     int inplace = 0;                   // C aliases A (tile-local product): the 128-tile must stay in one workgroup
+    int rows64 = 0;                    // 64-row strips of the 128-tile (two workgroups per tile; safe in place)
     int pair = 0;                      // k_end_tri, rectangular tile set, small tiles: column tiles paired for equal K
 };
 // Host-side construction of an L2-friendly order: the tile set is cut into S x S super-tiles; the

@@ -245,7 +245,7 @@ def main():
                        "cholesky_tflops": chol["flops"] / chol["ms"] / 1e9,
                        "cholesky_frac_of_fp64_mfma_peak": chol["flops"] / chol["ms"] / 1e9 / FP64_MFMA_PEAK_TFLOPS,
                        "cand_solve_tflops": solve["flops"] / solve["ms"] / 1e9},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<1, 128, 4, false> (C -= A B^T on fp64 v_mfma_f64_16x16x4_f64, 8 waves)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<1, 128, 4, false, 128> (C -= A B^T on fp64 v_mfma_f64_16x16x4_f64, 8 waves)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,

@@ -249,7 +249,7 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // events only around the launches that carry the flops (>= 1024 output tiles): bracketing every one of the
     // ~700 small launches of an iteration stalls the latency chain (34 -> 53 ms per factorisation, measured)
-    // ... and only the launches of ONE kernel symbol, gemm_nt_kernel<1, 128, 4, false> (C -= A B^T, 8 waves), so that the
+    // ... and only the launches of ONE kernel symbol, gemm_nt_kernel<1, 128, 4, false, 128> (C -= A B^T, 8 waves), so that the
     // average agrees with that symbol's row in a rocprofv3 --stats summary of the same command
     const bool timed = g->profiling && n >= g->profile_min_tiles &&
                        (g->profile_min_tiles < 1024 || (mode == 1 && oo.waves8 && !oo.small));  // tracing tools lower the threshold

@@ -183,7 +183,7 @@ int gp_comm_bcast_fit(gp_t *gp, int root);
 int gp_last_phases(gp_t *gp, int cap, const char **names, double *ms, double *flops, double *bytes);
 /* Dominant-kernel accounting (the fp64 MFMA GEMM): launches, summed device time (ms, HIP events around the launches
  * when profiling is on), algorithmic flops.  With the default threshold the events bracket exactly the launches of one
- * kernel symbol, gemm_nt_kernel<1, 128, 4, false> (C -= A B^T, >= 1400 output tiles), so that the average agrees with that
+ * kernel symbol, gemm_nt_kernel<1, 128, 4, false, 128> (C -= A B^T, >= 1400 output tiles), so that the average agrees with that
  * symbol's row of a rocprofv3 --stats summary; "profile_min_tiles" < 1024 brackets every launch above it instead
  * (tracing tools).  Reset by gp_profile(gp, 1). */
 int gp_profile(gp_t *gp, int on);

@@ -175,6 +175,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     gs = h.gemm_stats()
+    busy_ms = h.gemm_busy()
     phases_timed = {p["name"]: round(p["ms"], 3) for p in h.phases()}   # of the last call of the last timed step
     h.profile(False)
     if dist is not None:
@@ -251,10 +252,13 @@ def main():
                          "traffic_source": traffic_src,
                          "note": ("in gp_fit_predict three candidate-update launches and the trailing updates of the "
                                   "factorisation's tail run CONCURRENTLY (that is where the entry point gains its 5 %): their "
-                                  "durations, hence this average, include the time they share the chip; --separate-calls "
-                                  "times the same kernel without that overlap (0.73 of peak, profiles/)") if fused else None,
+                                  "durations, hence this average, include the time they share the chip; achieved_while_running = the "
+                                  "same flops / the union of the launches' intervals; --separate-calls times the same kernel "
+                                  "without overlap (0.74 of peak, profiles/)") if fused else None,
                          "launches": gs["launches"], "kernel_ms_total": gs["ms"],
                          "launch_filter": "every launch of that kernel symbol in the timed region (launches of >= 1400 output tiles: trailing updates, candidate updates; > 90 % of the flops)", "avg_launch_ms": gs["ms"] / max(gs["launches"], 1),
+                         "busy_ms_total": busy_ms, "achieved_while_running": gs["flops"] / max(busy_ms, 1e-9) / 1e9,
+                         "frac_while_running": gs["flops"] / max(busy_ms, 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS,
                          "flops_per_launch_avg": gs["flops"] / max(gs["launches"], 1)},
         }
         if world == 1 and not args.no_cpu_baseline:

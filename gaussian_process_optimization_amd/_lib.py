@@ -67,6 +67,7 @@ SIGNATURES = [
                                       c_double_p]),
     ("gp_profile", ctypes.c_int, [_vp, ctypes.c_int]),
     ("gp_gemm_stats", ctypes.c_int, [_vp, c_int64_p, c_double_p, c_double_p]),
+    ("gp_gemm_busy", ctypes.c_int, [_vp, c_double_p]),
     ("gp_gemm_trace", ctypes.c_int, [_vp, ctypes.c_int, c_int64_p, c_int_p, c_double_p]),
     ("gp_synchronize", ctypes.c_int, [_vp]),
     ("gp_set_option", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
@@ -324,6 +325,11 @@ class Handle(object):
         check(self.lib, self.lib.gp_gemm_stats(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)),
               "gp_gemm_stats")
         return dict(launches=n.value, ms=ms.value, flops=fl.value)
+
+    def gemm_busy(self):
+        b = ctypes.c_double()
+        check(self.lib, self.lib.gp_gemm_busy(self.h, ctypes.byref(b)), "gp_gemm_busy")
+        return b.value
 
     def gemm_trace(self, cap=100000):
         tiles = np.empty(cap, dtype=np.int64)

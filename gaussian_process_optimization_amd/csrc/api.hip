@@ -1314,6 +1314,40 @@ int gp_gemm_stats(gp_t *g, int64_t *launches, double *ms, double *flops) {
     return 0;
 }
 
+// Wall time during which at least one of the profiled launches was running (the union of their [start, end] intervals,
+// measured against the first profiled launch's start event).  With overlapping launches (gp_fit_predict) the SUM of the
+// durations counts shared time twice; flops / busy is the kernel's throughput while it runs.
+int gp_gemm_busy(gp_t *g, double *busy_ms) {
+    if (!g || !busy_ms) return fail(GP_ERR_ARG, "null argument");
+    hipSetDevice(g->device);
+    hipStreamSynchronize(g->s_panel);
+    if (g->s_bulk) hipStreamSynchronize(g->s_bulk);
+    if (g->s_inv) hipStreamSynchronize(g->s_inv);
+    if (g->s_pred) hipStreamSynchronize(g->s_pred);
+    hipStreamSynchronize(g->s);
+    std::vector<std::pair<double, double>> iv;
+    for (size_t i = 0; i + 1 < g->gemm_ev_used; i += 2) {
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, g->gemm_events[0], g->gemm_events[i]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&b, g->gemm_events[0], g->gemm_events[i + 1]) != hipSuccess) continue;
+        iv.emplace_back((double)a, (double)b);
+    }
+    std::sort(iv.begin(), iv.end());
+    double busy = 0.0, cur_a = 0.0, cur_b = -1.0;
+    for (auto &p : iv) {
+        if (cur_b < cur_a || p.first > cur_b) {
+            if (cur_b >= cur_a) busy += cur_b - cur_a;
+            cur_a = p.first;
+            cur_b = p.second;
+        } else if (p.second > cur_b) {
+            cur_b = p.second;
+        }
+    }
+    if (cur_b >= cur_a) busy += cur_b - cur_a;
+    *busy_ms = busy;
+    return 0;
+}
+
 int gp_gemm_trace(gp_t *g, int cap, int64_t *tiles, int *K, double *ms) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
     hipSetDevice(g->device);

@@ -188,6 +188,10 @@ int gp_last_phases(gp_t *gp, int cap, const char **names, double *ms, double *fl
  * (tracing tools).  Reset by gp_profile(gp, 1). */
 int gp_profile(gp_t *gp, int on);
 int gp_gemm_stats(gp_t *gp, int64_t *launches, double *ms, double *flops);
+/* wall time (ms) during which at least one profiled launch was running: the union of their intervals.  Launches of
+ * gp_fit_predict overlap, so the SUM of durations above counts shared time twice; flops / busy is the kernel's
+ * throughput while it runs. */
+int gp_gemm_busy(gp_t *gp, double *busy_ms);
 /* per-launch record of the profiled GEMM launches: output tiles, K (negative: triangular contraction), ms */
 int gp_gemm_trace(gp_t *gp, int cap, int64_t *tiles, int *K, double *ms);
 int gp_synchronize(gp_t *gp);

@@ -129,8 +129,8 @@ struct gp_ctx {
     int panel_tiles_tail = 0, tail_rows = 0;  // narrower factorisation panels once fewer than tail_rows row tiles remain
     int waves8 = 1;
     int stagger = 3;  // see gemm.hip: odd-slot workgroups start 3 * 1024 cycles late (+1.5 % measured)
-    int pipe_stages_grad = 8, pipe_start_pct_grad = 40;  // the same for gp_fit_grad (stages of the solve for L^-T)
-    int pipe_stages = 3;         // gp_fit_predict: candidate stages that ride behind the factorisation (rest afterwards)
+    int pipe_stages_grad = 0, pipe_start_pct_grad = 40;  // the same for gp_fit_grad (stages of the solve for L^-T)
+    int pipe_stages = 0;         // gp_fit_predict: candidate stages that ride behind the factorisation (rest afterwards)
     int pipe_done = 0;           // ... how many did, in the last factorisation
     int pipe_start_pct = 40;     // ... released once this share of the panels is factored (the chain sets the pace from there)
     std::vector<int> gemm_K;
@@ -407,13 +407,13 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         if (value < 0) return fail(GP_ERR_ARG, "profile_min_tiles < 0");
         g->profile_min_tiles = value;
     } else if (!strcmp(name, "pipe_stages_grad")) {
-        if (value < 1) return fail(GP_ERR_ARG, "pipe_stages_grad < 1");
+        if (value < 0) return fail(GP_ERR_ARG, "pipe_stages_grad < 0");
         g->pipe_stages_grad = (int)std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "pipe_start_pct_grad")) {
         if (value < 0 || value > 100) return fail(GP_ERR_ARG, "pipe_start_pct_grad out of range");
         g->pipe_start_pct_grad = (int)value;
     } else if (!strcmp(name, "pipe_stages")) {
-        if (value < 1) return fail(GP_ERR_ARG, "pipe_stages < 1");
+        if (value < 0) return fail(GP_ERR_ARG, "pipe_stages < 0");
         g->pipe_stages = (int)std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "lauum_panels")) {
         g->lauum_panels = (int)value;
@@ -874,7 +874,9 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         pp.T = g->dT;
         pp.S = g->dT2;
         pp.trapezoid = (pipe == 2);
-        pp.stages = pipe == 2 ? g->pipe_stages_grad : g->pipe_stages;
+        // 0 = automatic: the share of the panels that was best at N = 16384 (3 of 22 candidate stages, 8 of 22 L^-T stages)
+        pp.stages = pipe == 2 ? (g->pipe_stages_grad > 0 ? g->pipe_stages_grad : std::max(1, (nJ * 36 + 50) / 100))
+                              : (g->pipe_stages > 0 ? g->pipe_stages : std::max(1, (nJ * 14 + 50) / 100));
         pp.start_pct = pipe == 2 ? g->pipe_start_pct_grad : g->pipe_start_pct;
     }
     const double diag_add = g->noise + 1e-8;  // exact_gaussian_inference.py:56

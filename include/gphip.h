@@ -111,7 +111,7 @@ int gp_set_candidates(gp_t *gp, const double *Xs, int64_t M);
  *   mean[M,P] = K(Xs,X) alpha;  var[M] = variance - sum_rows (L^-1 K(X,Xs))^2 (+ noise).  No clipping. */
 int gp_predict(gp_t *gp, int include_noise, double *mean, double *var);
 
-/* gp_fit + gp_predict on the resident candidates as ONE call.  The first "pipe_stages" (default 3) panel stages of
+/* gp_fit + gp_predict on the resident candidates as ONE call.  The first "pipe_stages" (3 at N = 16384) panel stages of
  * the candidate solve ride behind the factorisation once "pipe_start_pct" % (default 40) of its panels are done --
  * from there the factorisation's latency chain leaves CUs idle -- and the rest run after it.  Bitwise the results of
  * the two calls in sequence; 5 % faster at N=16384, M=10^4 (BO.suggest_next_locations always runs the two back to
@@ -203,9 +203,10 @@ int gp_synchronize(gp_t *gp);
  *   "mc_max"             candidate rows per chunk (default 16384)
  *   "small_below", "chain_small_below"   launches with fewer 128-tiles run as 64x64 work units (1400 / 400 on the chain)
  *   "waves8", "stagger", "trsm_waves8", "supertile"   GEMM launch shape
- *   "pipe_stages", "pipe_start_pct"   gp_fit_predict: how many candidate stages ride behind the factorisation (3) and
+ *   "pipe_stages", "pipe_start_pct"   gp_fit_predict: how many candidate stages ride behind the factorisation (0 = automatic:
+ *                        14 % of the panels, 3 at N = 16384) and
  *                        after which share of its panels they are released (40)
- *   "pipe_stages_grad", "pipe_start_pct_grad"   the same for gp_fit_grad (8, 40)
+ *   "pipe_stages_grad", "pipe_start_pct_grad"   the same for gp_fit_grad (0 = automatic: 36 % of the panels; 40)
  *   "lauum_panels"       Ky^-1 product accumulated per k-panel (default 1)
  *   "pair_tri"           triangular-K products: column tiles paired for equal contraction length (default 2)
  *   "fmin_direct"        gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha (default 0)

@@ -121,6 +121,7 @@ struct gp_ctx {
     int small_below = 1400;  // launches with fewer 128-tiles than this use 64x64 workgroup tiles
     int chain_small_below = 400;  // ... the same threshold for the launches of the factorisation's chain stream
     int lauum_panels = 1;    // Ky^-1 product accumulated per k-panel (0: one launch over the whole contraction)
+    int side_alpha = 1;      // alpha / log det on the side stream while stages of the one-call entry points still run
     int pair_tri = 2;        // triangular-K products: pair column tiles c and W-1-c in one workgroup (1: 64x64 units only)
     int fmin_direct = 0;     // gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha
     int inner_left_rows = 1 << 30;  // panels with at least this many row tiles update their columns left-looking
@@ -418,6 +419,8 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "lauum_panels")) {
         g->lauum_panels = (int)value;
         g->wi_valid = false;
+    } else if (!strcmp(name, "side_alpha")) {
+        g->side_alpha = (int)value;
     } else if (!strcmp(name, "pair_tri")) {
         g->pair_tri = (int)value;
     } else if (!strcmp(name, "fmin_direct")) {
@@ -938,6 +941,14 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         g->nphases = 0;
     }
     g->jitter = jitter;
+    // alpha = L^-T z, log det and alpha'y: 45 short dependent launches (latency-bound, 1 ms).  When candidate / L^-T
+    // stages are still to run on the main stream they go on the side stream instead, beside those long launches.
+    bool side_alpha = false;
+    auto alpha_lml = [&](hipStream_t st) {
+        launch_logdet(st, g->dA, lda, N, g->dScal);
+        launch_trsv_backward(st, g->dA, lda, g->dInvP, g->invp_W, Npad, g->dA + Npad * lda, lda, P, g->dAlpha, g->dW);
+        hipLaunchKernelGGL(dot_ay_kernel, dim3(P), dim3(1024), 0, st, g->dAlpha, Npad, g->dY, N, P, g->dScal + 8);
+    };
     if (pipe) {
         const int W = std::min(g->panel_tiles, nt_);
         const int nJ = (nt_ + W - 1) / W;
@@ -948,6 +959,14 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
             int phr = phase_begin(g, pipe == 2 ? "potri_solve_rest" : "cand_solve_rest", 0.0, 0.0);
             int rci = ensure_panel_inv(g);
             if (rci) return rci;
+            if (g->s_inv && g->side_alpha) {
+                hipEvent_t eI = la_event(g, 3000);
+                hipEventRecord(eI, g->s);
+                hipStreamWaitEvent(g->s_inv, eI, 0);
+                alpha_lml(g->s_inv);
+                hipEventRecord(la_event(g, 3001), g->s_inv);
+                side_alpha = true;
+            }
             solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), pipe == 2 ? 1 : 0, g->pipe_done);
             phase_end(g, phr);
         }
@@ -959,13 +978,13 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     }
 
     int ph = phase_begin(g, "alpha_lml", 2.0 * (double)N * N * P, 8.0 * (double)N * N / 2);
-    launch_logdet(g->s, g->dA, lda, N, g->dScal);
-    {
+    if (side_alpha) {
+        hipStreamWaitEvent(g->s, la_event(g, 3001), 0);
+    } else {
         int rci = ensure_panel_inv(g);
         if (rci) return rci;
+        alpha_lml(g->s);
     }
-    launch_trsv_backward(g->s, g->dA, lda, g->dInvP, g->invp_W, Npad, g->dA + Npad * lda, lda, P, g->dAlpha, g->dW);
-    hipLaunchKernelGGL(dot_ay_kernel, dim3(P), dim3(1024), 0, g->s, g->dAlpha, Npad, g->dY, N, P, g->dScal + 8);
     phase_end(g, ph);
     if (pipe == 1) {
         ph = phase_begin(g, "reduce", 0.0, 8.0 * (double)N * g->M);

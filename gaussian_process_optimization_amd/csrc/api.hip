@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <functional>
 #include <array>
 #include <map>
 #include <mutex>
@@ -588,6 +589,7 @@ struct PredPipe {
     bool on = false;
     int mt = 0;          // candidate row tiles
     double *T = nullptr, *S = nullptr;
+    std::function<void(hipStream_t)> init;  // fills T (cross covariance / identity) on the candidate stream, beside the factorisation's head
     bool trapezoid = false;  // T is block upper-triangular (the identity: the solve for L^-T), row tiles above the panel's end only
     int stages = 0, start_pct = 0;
 };
@@ -628,6 +630,7 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     if (pp.on) {
         hipStreamWaitEvent(g->s_inv, e0, 0);
         hipStreamWaitEvent(g->s_pred, e0, 0);
+        if (pp.init) pp.init(g->s_pred);
     }
     // events: 1 + 2J = chain(J) done, 2 + 2J = bulk(J) done; 1000 + J = invP_J built
     int next_pred = 0;
@@ -903,15 +906,15 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         phase_end(g, ph);
         HIPCHK(hipMemsetAsync(g->dInfo, 0, sizeof(int) * 4, g->s));
         if (pipe == 1) {
-            ph = phase_begin(g, "cross_k", 0.0, 8.0 * (double)(N + g->M) * g->D + 8.0 * (double)N * g->M);
-            launch_cross_k(g->s, g->dT, Npad, g->dXs, g->M, mcpad, g->dX, N, Npad, g->kp);
-            phase_end(g, ph);
+            pp.init = [g, mcpad, N, Npad](hipStream_t st) {
+                launch_cross_k(st, g->dT, Npad, g->dXs, g->M, mcpad, g->dX, N, Npad, g->kp);
+            };
             ph = phase_begin(g, "cholesky+cand_solve", (double)N * N * N / 3.0 + (double)N * N * g->M, 0.0);
             int rcf = factor_lookahead(g, pp);
             if (rcf) return rcf;
         } else if (pipe == 2) {
             ph = phase_begin(g, "cholesky+potri_stages", (double)N * N * N / 3.0, 0.0);
-            launch_set_identity(g->s, g->dT, Npad, Npad);
+            pp.init = [g, Npad](hipStream_t st) { launch_set_identity(st, g->dT, Npad, Npad); };
             int rcf = factor_lookahead(g, pp);
             if (rcf) return rcf;
         } else {

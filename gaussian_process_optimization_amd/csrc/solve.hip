@@ -163,16 +163,25 @@ __global__ __launch_bounds__(256) void predict_reduce_kernel(const double *T, lo
     const long c = blockIdx.x;
     const double *t = T + c * ldt;
     const long n2 = N >> 1;
-    double s = 0.0;
+    double s = 0.0, m0 = 0.0;
+    // one pass over the row: sum of squares and the first output's mean together (P = 1 is the BO case)
     for (long i = threadIdx.x; i < n2; i += 256) {
         const double2_t x = *(const double2_t *)(t + 2 * i);
+        const double2_t y = *(const double2_t *)(Z + 2 * i);
         s = fma(x[0], x[0], s);
         s = fma(x[1], x[1], s);
+        m0 = fma(x[0], y[0], m0);
+        m0 = fma(x[1], y[1], m0);
     }
-    if ((N & 1) && threadIdx.x == 0) s = fma(t[N - 1], t[N - 1], s);
+    if ((N & 1) && threadIdx.x == 0) {
+        s = fma(t[N - 1], t[N - 1], s);
+        m0 = fma(t[N - 1], Z[N - 1], m0);
+    }
     s = block_sum<256>(s, sh);
     if (threadIdx.x == 0) var[c] = (kss - s) + noise_add;
-    for (int p = 0; p < P; ++p) {
+    m0 = block_sum<256>(m0, sh);
+    if (threadIdx.x == 0) mean[c * P] = m0;
+    for (int p = 1; p < P; ++p) {
         const double *z = Z + p * ldz;
         double m = 0.0;
         for (long i = threadIdx.x; i < n2; i += 256) {

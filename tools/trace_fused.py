@@ -13,3 +13,6 @@ for k in range(0, len(pot), 12):
 for q in sorted(set(r["Queue_Id"] for r in last)):
     rs = [r for r in last if r["Queue_Id"] == q]
     print("queue %s: %4d kernels, busy %.2f ms, first %.2f last %.2f" % (q, len(rs), sum(E(r) - S(r) for r in rs), S(rs[0]), E(rs[-1])))
+big = [r for r in last if E(r) - S(r) > 0.25]
+for r in big:
+    print("  q=%s %7.2f -> %7.2f (%6.2f ms) wg %7d %s" % (r["Queue_Id"], S(r), E(r), E(r) - S(r), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Kernel_Name"][:40]))

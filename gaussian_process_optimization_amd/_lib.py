@@ -29,6 +29,14 @@ SIGNATURES = [
     ("gp_device_info", ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, c_int_p, c_int64_p]),
     ("gp_create", ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),
     ("gp_destroy", ctypes.c_int, [_vp]),
+    ("gp_shutdown", ctypes.c_int, []),
+    ("gp_get_fit_state", ctypes.c_int, [_vp, c_double_p, c_double_p, c_double_p]),
+    ("gp_get_dl_dk", ctypes.c_int, [_vp, c_double_p]),
+    ("gp_posterior_samples", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p,
+                                            c_double_p, c_double_p]),
+    ("gp_acq_topk", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                   ctypes.c_double, ctypes.c_int, ctypes.c_int, c_int64_p, c_double_p]),
+    ("gp_comm_allgather_topk", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_int64_p, c_double_p, c_int64_p]),
     ("gp_set_data", ctypes.c_int, [_vp, c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     ("gp_set_params", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_double]),
     ("gp_set_gower", ctypes.c_int, [_vp, ctypes.c_int, c_int_p, c_double_p]),
@@ -205,6 +213,38 @@ class Handle(object):
         check(self.lib, rc, "gp_fit_grad")
         return (lml.value, logdet.value, jit.value), (dv.value, dl, dn.value)
 
+    def fit_state(self):
+        lml, logdet, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        check(self.lib, self.lib.gp_get_fit_state(self.h, ctypes.byref(lml), ctypes.byref(logdet), ctypes.byref(jit)),
+              "gp_get_fit_state")
+        return lml.value, logdet.value, jit.value
+
+    def dL_dK(self):
+        out = np.empty((self.N, self.N))
+        check(self.lib, self.lib.gp_get_dl_dk(self.h, dptr(out)), "gp_get_dl_dk")
+        return out
+
+    def posterior_samples(self, Z, include_noise=False, maxtries=5):
+        """Z[S, M] standard normals -> (mean[M, P], dev[S, M], jitter): draw s of output d = mean[:, d] + dev[s]."""
+        Z = as_f64(Z, 2)
+        if Z.shape[1] != self.M:
+            raise ValueError("Z needs one column per resident candidate")
+        mean = np.empty((self.M, self.P))
+        dev = np.empty((Z.shape[0], self.M))
+        jit = ctypes.c_double()
+        rc = self.lib.gp_posterior_samples(self.h, int(bool(include_noise)), dptr(Z), Z.shape[0], int(maxtries),
+                                           dptr(mean), dptr(dev), ctypes.byref(jit))
+        check(self.lib, rc, "gp_posterior_samples")
+        return mean, dev, jit.value
+
+    def acq_topk(self, type_, par, fmin, sense, k, y_mean=0.0, y_std=1.0):
+        idx = np.empty(k, dtype=np.int64)
+        val = np.empty(k)
+        check(self.lib, self.lib.gp_acq_topk(self.h, int(type_), float(par), float(fmin), float(y_mean), float(y_std),
+                                             int(sense), int(k), idx.ctypes.data_as(c_int64_p), dptr(val)),
+              "gp_acq_topk")
+        return idx, val
+
     def alpha(self):
         out = np.empty((self.N, self.P))
         check(self.lib, self.lib.gp_get_alpha(self.h, dptr(out)), "gp_get_alpha")
@@ -359,6 +399,16 @@ class Handle(object):
         check(self.lib, self.lib.gp_comm_allgather_best(self.h, float(val), int(idx), dptr(vals),
                                                         idxs.ctypes.data_as(c_int64_p)), "gp_comm_allgather_best")
         return vals, idxs
+
+    def comm_allgather_topk(self, vals, idxs, nranks):
+        vals = as_f64(vals, 1)
+        idxs = np.ascontiguousarray(idxs, dtype=np.int64)
+        k = vals.size
+        av = np.empty(nranks * k)
+        ai = np.empty(nranks * k, dtype=np.int64)
+        check(self.lib, self.lib.gp_comm_allgather_topk(self.h, k, dptr(vals), idxs.ctypes.data_as(c_int64_p), dptr(av),
+                                                        ai.ctypes.data_as(c_int64_p)), "gp_comm_allgather_topk")
+        return av, ai
 
     def comm_bcast_fit(self, root=0):
         check(self.lib, self.lib.gp_comm_bcast_fit(self.h, int(root)), "gp_comm_bcast_fit")

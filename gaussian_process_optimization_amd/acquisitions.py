@@ -114,6 +114,20 @@ class AcquisitionBase(object):
         i = int(np.argmin(a) if sense < 0 else np.argmax(a))
         return i, float(a[i])
 
+    def topk(self, x, k, sense=-1):
+        """The ``k`` best rows of ``acquisition_function(x)`` in order, (indices, values): what
+        ``AnchorPointsGenerator.get`` keeps (anchor_points_generator.py:59-61, ``argsort(scores)[:num_anchor]``).
+        Equal scores come out lowest index first; fewer than ``k`` rows -> the tail is index -1."""
+        if self._device_ok() and k <= 64:
+            gp, fmin, y_mean, y_std = self._device_stage(x)
+            return gp._h.acq_topk(self._acq_id, self._par(), fmin, sense, k, y_mean, y_std)
+        a = self.acquisition_function(x)[:, 0]
+        order = np.argsort(a if sense < 0 else -a, kind="stable")[:k]
+        idx = np.full(k, -1, dtype=np.int64)
+        val = np.full(k, np.inf if sense < 0 else -np.inf)
+        idx[:order.size], val[:order.size] = order, a[order]
+        return idx, val
+
     def optimize(self, duplicate_manager=None):
         """base.py:52-60."""
         if not self.analytical_gradient_acq:

@@ -359,14 +359,17 @@ class BayesianOptimization(object):
             raise ValueError("Cannot run the optimization loop without the objective function")
         t0 = time.time()
         it = 0
-        while it < max_iter and (time.time() - t0) < max_time:
+        while (time.time() - t0) < max_time:
             try:
                 self._update_model()
             except np.linalg.LinAlgError:
                 break                                  # bo.py:134-137
+            # bo.py:139-141: the model is refreshed first, then the budget and the distance between the LAST TWO
+            # evaluated points decide (the point that triggers the rule has been evaluated and is kept)
+            if it >= max_iter or (self.X.shape[0] > 1 and
+                                  np.sqrt(np.sum((self.X[-1, :] - self.X[-2, :]) ** 2)) <= eps):
+                break
             x = self._compute_next_evaluations()
-            if self.X.shape[0] > 0 and np.sqrt(np.sum((x - self.X[-1]) ** 2)) <= eps:
-                break                                  # bo.py:161-164 (distance stopping rule)
             y = self._evaluate(x)
             self.X = np.vstack((self.X, x))
             self.Y = np.vstack((self.Y, y))

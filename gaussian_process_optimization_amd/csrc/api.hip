@@ -11,6 +11,7 @@
 #include <array>
 #include <map>
 #include <mutex>
+#include <set>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -56,7 +57,8 @@ struct gp_ctx {
     hipStream_t s_bulk = nullptr;  // trailing-update stream of the look-ahead Cholesky: masked off the reserved CUs
     int bulk_reserved = -1;        // reserved-CU count s_bulk was created with
     hipStream_t s_inv = nullptr, s_pred = nullptr;  // pipelined candidate solve (gp_fit_predict), low priority
-    std::vector<hipEvent_t> la_events;
+    // stream-ordering events of the look-ahead factorisation, one dense vector per role (EV_* below)
+    std::vector<hipEvent_t> la_events[4];
     // data
     long N = 0, Npad = 0;
     int D = 0, P = 0;
@@ -144,10 +146,14 @@ struct gp_ctx {
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    double *dComm = nullptr;  // gather scratch of the top-k exchange
+    long capComm = 0;
+    bool dead = false;  // gp_shutdown ran: the device's streams are gone, only gp_destroy is still valid
 };
 
 static int ensure_bulk_stream(gp_ctx *g);
-static hipEvent_t la_event(gp_ctx *g, size_t i);
+enum { EV_CHAIN = 0, EV_BULK = 1, EV_INVP = 2, EV_MISC = 3 };  // chain(J) done, bulk(J) done, invP_J built, fork/join/side
+static hipEvent_t la_event(gp_ctx *g, int kind, size_t i);
 
 // One set of HIP streams per device for the whole process, created once in a fixed order and never destroyed.
 // Hardware queues are dealt over the command processor's pipes in creation order, and two queues on one pipe do
@@ -161,6 +167,41 @@ struct DevStreams {
 };
 static std::mutex g_ds_mu;
 static std::map<int, DevStreams> g_ds;
+static std::set<gp_ctx *> g_live;  // contexts created and not yet destroyed
+static bool g_atexit_registered = false;
+
+static void destroy_ctx_events(gp_ctx *g);
+
+// Ordered shutdown (exported as gp_shutdown, and registered with atexit() at the first stream creation so that it runs
+// BEFORE the HIP runtime's and a profiler's own exit handlers, which were registered earlier): quiesce every device the
+// library touched, destroy the events recorded on the shared streams, then the streams.  Without it the five
+// process-lifetime queues per device -- two of them created with hipExtStreamCreateWithCUMask -- were still alive when
+// the runtime's static destructors ran; under rocprofv3 the runtime's queue teardown then called into the already
+// finalised tool and the process died with SIGSEGV inside __cxa_finalize (round 1: every profiled run after the
+// per-device stream set was introduced; plain runs exited 0).  See DESIGN.md, "Lifecycle".
+static void shutdown_all() {
+    std::lock_guard<std::mutex> lk(g_ds_mu);
+    for (auto &kv : g_ds) {
+        if (hipSetDevice(kv.first) != hipSuccess) continue;
+        hipDeviceSynchronize();
+    }
+    for (gp_ctx *g : g_live) {
+        hipSetDevice(g->device);
+        destroy_ctx_events(g);
+        g->s = g->s_panel = g->s_bulk = g->s_inv = g->s_pred = nullptr;
+        g->dead = true;
+    }
+    for (auto &kv : g_ds) {
+        if (hipSetDevice(kv.first) != hipSuccess) continue;
+        DevStreams &d = kv.second;
+        for (hipStream_t *st : {&d.pred, &d.inv, &d.bulk, &d.panel, &d.s}) {
+            if (*st) hipStreamDestroy(*st);
+            *st = nullptr;
+        }
+    }
+    g_ds.clear();
+}
+static void shutdown_atexit() { shutdown_all(); }
 
 static int make_bulk_stream(int device, int reserve, hipStream_t *out) {
     hipDeviceProp_t pr;
@@ -185,6 +226,10 @@ static int get_streams(int device, int reserve, DevStreams *out) {
     if (const char *e = getenv("GPHIP_RESERVE_CUS")) reserve = std::max(0, std::min(64, atoi(e)));
     DevStreams &d = g_ds[device];
     if (!d.s) {
+        if (!g_atexit_registered) {
+            atexit(shutdown_atexit);
+            g_atexit_registered = true;
+        }
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIPCHK(hipStreamCreateWithPriority(&d.s, hipStreamNonBlocking, lo));
@@ -361,40 +406,76 @@ int gp_create(gp_t **out, int device) {
         g->s_inv = d.inv;
         g->s_pred = d.pred;
     }
-    HIPCHK(hipMalloc((void **)&g->dInfo, sizeof(int) * 4));
-    HIPCHK(hipMalloc((void **)&g->dScal, sizeof(double) * 512));
-    HIPCHK(hipMalloc((void **)&g->dRedV, sizeof(double) * 512));
-    HIPCHK(hipMalloc((void **)&g->dRedI, sizeof(long long) * 1024));
+    hipError_t e = hipMalloc((void **)&g->dInfo, sizeof(int) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->dScal, sizeof(double) * 512);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->dRedV, sizeof(double) * 512);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->dRedI, sizeof(long long) * 1024);
+    if (e != hipSuccess) {
+        if (g->dInfo) hipFree(g->dInfo);
+        for (double *p : {g->dScal, g->dRedV})
+            if (p) hipFree(p);
+        if (g->dRedI) hipFree(g->dRedI);
+        delete g;
+        return fail(GP_ERR_HIP, "gp_create: hipMalloc -> %s", hipGetErrorString(e));
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_ds_mu);
+        g_live.insert(g);
+    }
     *out = g;
     return 0;
 }
 
-int gp_destroy(gp_t *g) {
-    if (!g) return 0;
-    hipSetDevice(g->device);
-    hipDeviceSynchronize();
-    if (g->comm) ncclCommDestroy(g->comm);
-    double *ptrs[] = {g->dX, g->dY, g->dA, g->dInvL, g->dAlpha, g->dW, g->dMu, g->dScal, g->dRedV,
-                      g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi, g->dT2, g->dDm, g->dDv, g->dDacq, g->dCov, g->dInvP, g->dInvPw, g->dLp};
-    for (double *p : ptrs)
-        if (p) hipFree(p);
-    if (g->dInfo) hipFree(g->dInfo);
-    if (g->dRedI) hipFree(g->dRedI);
+int gp_shutdown(void) {
+    shutdown_all();
+    return 0;
+}
+
+static void destroy_ctx_events(gp_ctx *g) {
     for (int i = 0; i < MAX_PHASES; ++i)
         if (g->phases[i].used) {
             hipEventDestroy(g->phases[i].e0);
             hipEventDestroy(g->phases[i].e1);
+            g->phases[i].used = false;
         }
+    g->nphases = 0;
     for (hipEvent_t e : g->gemm_events) hipEventDestroy(e);
+    g->gemm_events.clear();
+    g->gemm_ev_used = 0;
+    g->gemm_tiles.clear();
+    g->gemm_K.clear();
+    for (auto &v : g->la_events) {
+        for (hipEvent_t e : v) hipEventDestroy(e);
+        v.clear();
+    }
+}
+
+int gp_destroy(gp_t *g) {
+    if (!g) return 0;
+    {
+        std::lock_guard<std::mutex> lk(g_ds_mu);
+        if (!g_live.erase(g)) return 0;  // not a live context (double destroy)
+    }
+    hipSetDevice(g->device);
+    hipDeviceSynchronize();
+    if (g->comm) ncclCommDestroy(g->comm);
+    double *ptrs[] = {g->dX, g->dY, g->dA, g->dInvL, g->dAlpha, g->dW, g->dMu, g->dScal, g->dRedV,
+                      g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi, g->dT2, g->dDm, g->dDv, g->dDacq, g->dCov, g->dInvP, g->dInvPw, g->dLp, g->dComm};
+    for (double *p : ptrs)
+        if (p) hipFree(p);
+    if (g->dInfo) hipFree(g->dInfo);
+    if (g->dRedI) hipFree(g->dRedI);
     for (auto &kv : g->tile_lists) hipFree(kv.second);
-    // streams belong to the per-device set shared by every context of the process
-    for (hipEvent_t e : g->la_events) hipEventDestroy(e);
+    // events recorded on the shared streams go first; the streams themselves belong to the per-device set shared by
+    // every context of the process and are destroyed by gp_shutdown / the exit hook
+    destroy_ctx_events(g);
     delete g;
     return 0;
 }
 
 int gp_set_option(gp_t *g, const char *name, int64_t value) {
     if (!g || !name) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!strcmp(name, "panel_tiles")) {
         if (value < 1 || value > 64) return fail(GP_ERR_ARG, "panel_tiles out of range");
         g->panel_tiles = (int)value;
@@ -461,6 +542,7 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
 
 int gp_synchronize(gp_t *g) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(hipStreamSynchronize(g->s_panel));
     if (g->s_bulk) HIPCHK(hipStreamSynchronize(g->s_bulk));
@@ -472,6 +554,7 @@ int gp_synchronize(gp_t *g) {
 
 int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N, int D, int P) {
     if (!g || !X || !Y) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (N < 1 || D < 1 || D > GP_MAX_D || P < 1 || P > GP_MAX_RHS)
         return fail(GP_ERR_ARG, "bad shape N=%ld D=%d P=%d (D <= %d, P <= %d)", (long)N, D, P, GP_MAX_D, GP_MAX_RHS);
     HIPCHK(hipSetDevice(g->device));
@@ -518,6 +601,7 @@ int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N, int D, int
 // gp_predict_grad return GP_ERR_STATE for a Gower model).
 int gp_set_gower(gp_t *g, int enable, const int *is_discrete, const double *range) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->have_data) return fail(GP_ERR_STATE, "gp_set_data first");
     if (enable && (!is_discrete || !range)) return fail(GP_ERR_ARG, "null argument");
     g->kp.gower = enable ? 1 : 0;
@@ -536,6 +620,7 @@ int gp_set_gower(gp_t *g, int enable, const int *is_discrete, const double *rang
 
 int gp_set_params(gp_t *g, int kernel, int ard, double variance, const double *lengthscale, double noise) {
     if (!g || !lengthscale) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->have_data) return fail(GP_ERR_STATE, "gp_set_data must precede gp_set_params");
     if (kernel != GP_KERNEL_RBF && kernel != GP_KERNEL_MATERN52) return fail(GP_ERR_ARG, "unknown kernel %d", kernel);
     g->kp.kernel = kernel;
@@ -554,19 +639,16 @@ int gp_set_params(gp_t *g, int kernel, int ard, double variance, const double *l
 }
 
 // ---- blocked right-looking Cholesky (two-level: 128-column steps inside panel_tiles-wide panels) ----
-static void factor(gp_ctx *g) {
-    const long lda = g->Npad;
-    const int nt = (int)(g->Npad / GP_TILE);
-    const int R1 = nt + 1;  // row tiles incl. the RHS tile
+// A: nt x nt tiles (lower) plus R1 - nt extra row tiles that ride through the panel solves and updates (the RHS rows)
+static void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, int *info) {
     const int W = g->panel_tiles;
-    double *A = g->dA;
     hipStream_t s = g->s;
     for (int J0 = 0; J0 < nt; J0 += W) {
         const int J1 = std::min(J0 + W, nt);
         for (int j = J0; j < J1; ++j) {
-            launch_potrf_tile(s, A, lda, j, g->dInvL, g->dInfo);
+            launch_potrf_tile(s, A, lda, j, invL, info);
             // panel solve: A[i, j] <- A[i, j] * inv(L_jj)^T for the row tiles below (and the RHS tile)
-            gemm(g, s, 0, A, lda, A + (long)j * GP_TILE, lda, g->dInvL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0,
+            gemm(g, s, 0, A, lda, A + (long)j * GP_TILE, lda, invL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0,
                  GP_TILE, TileSet{j + 1, R1, j, j + 1, 0}, inplace_opt());
             // update of the remaining columns of this panel (K = 128)
             if (j + 1 < J1)
@@ -578,6 +660,11 @@ static void factor(gp_ctx *g) {
             gemm(g, s, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, (J1 - J0) * GP_TILE,
                  TileSet{0, R1, J1, nt, 1});
     }
+}
+
+static void factor(gp_ctx *g) {
+    const int nt = (int)(g->Npad / GP_TILE);
+    factor_buf(g, g->dA, g->Npad, nt, nt + 1, g->dInvL, g->dInfo);
 }
 
 // Pipelined candidate solve (gp_fit_predict): as soon as panel J of L is final (chain(J) done), two more
@@ -622,7 +709,7 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     double *A = g->dA;
     hipStream_t sp = g->s_panel, sb = g->s_bulk;
     // fork
-    hipEvent_t e0 = la_event(g, 0);
+    hipEvent_t e0 = la_event(g, EV_MISC, 0);
     hipEventRecord(e0, g->s);
     hipStreamWaitEvent(sp, e0, 0);
     hipStreamWaitEvent(sb, e0, 0);
@@ -632,7 +719,6 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
         hipStreamWaitEvent(g->s_pred, e0, 0);
         if (pp.init) pp.init(g->s_pred);
     }
-    // events: 1 + 2J = chain(J) done, 2 + 2J = bulk(J) done; 1000 + J = invP_J built
     int next_pred = 0;
     const int nJu = (nt + W - 1) / W;
     // Only the first `pipe_stages` candidate stages ride behind the factorisation (on the CU-masked stream, released
@@ -669,14 +755,14 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
                 gemm(g, sp, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE,
                      TileSet{0, R1, j + 1, J1, 1});
         }
-        hipEvent_t eF = la_event(g, 1 + 2 * J);
+        hipEvent_t eF = la_event(g, EV_CHAIN, J);
         hipEventRecord(eF, sp);
         const int K = (J1 - J0) * GP_TILE;
         if (pp.on) {
             if (J < pstages) {
                 hipStreamWaitEvent(g->s_inv, eF, 0);
                 build_panel_inv_one(g, g->s_inv, J, W, nt);
-                hipEventRecord(la_event(g, 1000 + J), g->s_inv);
+                hipEventRecord(la_event(g, EV_INVP, J), g->s_inv);
             }
             // Two concurrent MFMA-bound launches run slower than one after the other (measured 51 vs 63 TFLOP/s), and
             // the candidate stream is CU-masked like the trailing update (the diagonal-tile workgroup needs an empty
@@ -689,8 +775,8 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
                     const int Q = next_pred, Q0 = Q * W, Q1 = std::min(Q0 + W, nt);
                     const int KQ = (Q1 - Q0) * GP_TILE;
                     const int prow = pp.trapezoid ? std::min(pp.mt, Q1) : pp.mt;
-                    hipStreamWaitEvent(g->s_pred, la_event(g, 1 + 2 * J), 0);
-                    hipStreamWaitEvent(g->s_pred, la_event(g, 1000 + Q), 0);
+                    hipStreamWaitEvent(g->s_pred, la_event(g, EV_CHAIN, J), 0);
+                    hipStreamWaitEvent(g->s_pred, la_event(g, EV_INVP, Q), 0);
                     GemmOpt o;
                     o.k_end_tri = 1;
                     o.b_sub = Q0;
@@ -705,25 +791,25 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
         if (J1 >= nt) break;
         // the look-ahead update is on the critical path: enqueue it before the trailing update so that its
         // workgroups reach the dispatcher first once bulk(J-1) has drained
-        if (J >= 1) hipStreamWaitEvent(sp, la_event(g, 2 + 2 * (J - 1)), 0);
+        if (J >= 1) hipStreamWaitEvent(sp, la_event(g, EV_BULK, J - 1), 0);
         gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
              TileSet{0, R1, J1, J2, 1});
         if (J2 < nt) {
             hipStreamWaitEvent(sb, eF, 0);
             gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
                  TileSet{0, R1, J2, nt, 1});
-            hipEventRecord(la_event(g, 2 + 2 * J), sb);
+            hipEventRecord(la_event(g, EV_BULK, J), sb);
         }
     }
     // join
-    hipEvent_t ep = la_event(g, 1 + 2 * nJ + 1), eb = la_event(g, 1 + 2 * nJ + 2);
+    hipEvent_t ep = la_event(g, EV_MISC, 1), eb = la_event(g, EV_MISC, 2);
     hipEventRecord(ep, sp);
     hipEventRecord(eb, sb);
     hipStreamWaitEvent(g->s, ep, 0);
     hipStreamWaitEvent(g->s, eb, 0);
     g->pipe_done = pstages;
     if (pp.on) {
-        hipEvent_t eq = la_event(g, 1 + 2 * nJ + 3), ei = la_event(g, 1 + 2 * nJ + 4);
+        hipEvent_t eq = la_event(g, EV_MISC, 3), ei = la_event(g, EV_MISC, 4);
         hipEventRecord(eq, g->s_pred);
         hipEventRecord(ei, g->s_inv);
         hipStreamWaitEvent(g->s, eq, 0);
@@ -750,13 +836,14 @@ static int ensure_bulk_stream(gp_ctx *g) {
     return 0;
 }
 
-static hipEvent_t la_event(gp_ctx *g, size_t i) {
-    while (g->la_events.size() <= i) {
+static hipEvent_t la_event(gp_ctx *g, int kind, size_t i) {
+    std::vector<hipEvent_t> &v = g->la_events[kind];
+    while (v.size() <= i) {
         hipEvent_t e;
         hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        g->la_events.push_back(e);
+        v.push_back(e);
     }
-    return g->la_events[i];
+    return v[i];
 }
 
 // ---- inverted diagonal panels ---------------------------------------------------------------------
@@ -856,8 +943,21 @@ static int wi_lauum(gp_ctx *g);
 
 // Shared body of gp_fit and gp_fit_predict.  pipe != 0: the candidate solve of the resident candidates is
 // pipelined behind the factorisation (PredPipe above) and the posterior reductions are appended.
+// Any error return of fit_impl after work was forked onto the side streams must leave them joined: the guard waits for
+// every stream of the context unless the normal exit (where the joins are stream-ordered) dismissed it.
+struct QuiesceOnError {
+    gp_ctx *g;
+    bool armed = true;
+    ~QuiesceOnError() {
+        if (!armed) return;
+        for (hipStream_t st : {g->s_panel, g->s_bulk, g->s_inv, g->s_pred, g->s})
+            if (st) hipStreamSynchronize(st);
+    }
+};
+
 static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     HIPCHK(hipSetDevice(g->device));
+    QuiesceOnError guard{g};
     const long N = g->N, Npad = g->Npad, lda = g->Npad;
     const int P = g->P;
     const int nt_ = (int)(Npad / GP_TILE);
@@ -963,11 +1063,11 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
             int rci = ensure_panel_inv(g);
             if (rci) return rci;
             if (g->s_inv && g->side_alpha) {
-                hipEvent_t eI = la_event(g, 3000);
+                hipEvent_t eI = la_event(g, EV_MISC, 5);
                 hipEventRecord(eI, g->s);
                 hipStreamWaitEvent(g->s_inv, eI, 0);
                 alpha_lml(g->s_inv);
-                hipEventRecord(la_event(g, 3001), g->s_inv);
+                hipEventRecord(la_event(g, EV_MISC, 6), g->s_inv);
                 side_alpha = true;
             }
             solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), pipe == 2 ? 1 : 0, g->pipe_done);
@@ -982,7 +1082,7 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
 
     int ph = phase_begin(g, "alpha_lml", 2.0 * (double)N * N * P, 8.0 * (double)N * N / 2);
     if (side_alpha) {
-        hipStreamWaitEvent(g->s, la_event(g, 3001), 0);
+        hipStreamWaitEvent(g->s, la_event(g, EV_MISC, 6), 0);
     } else {
         int rci = ensure_panel_inv(g);
         if (rci) return rci;
@@ -1008,11 +1108,13 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         g->predicted = true;
         g->predicted_noise = include_noise ? 1 : 0;
     }
+    guard.armed = false;
     return 0;
 }
 
 int gp_fit(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_used) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit");
     int rc = fit_impl(g, maxtries, 0, 0);
     if (rc) return rc;
@@ -1030,6 +1132,7 @@ static int run_predict(gp_ctx *g, int include_noise);
 int gp_fit_predict(gp_t *g, int maxtries, int include_noise, double *lml, double *logdet, double *jitter_used,
                    double *mean, double *var) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit_predict");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     HIPCHK(hipSetDevice(g->device));
@@ -1054,6 +1157,7 @@ int gp_fit_predict(gp_t *g, int maxtries, int include_noise, double *lml, double
 
 int gp_get_alpha(gp_t *g, double *alpha) {
     if (!g || !alpha) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     HIPCHK(hipSetDevice(g->device));
     std::vector<double> tmp((size_t)g->P * g->Npad);
@@ -1065,6 +1169,7 @@ int gp_get_alpha(gp_t *g, double *alpha) {
 
 int gp_get_chol(gp_t *g, double *L) {
     if (!g || !L) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     HIPCHK(hipSetDevice(g->device));
     const long N = g->N;
@@ -1077,6 +1182,7 @@ int gp_get_chol(gp_t *g, double *L) {
 
 int gp_kernel_matrix(gp_t *g, double *K) {
     if (!g || !K) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params first");
     HIPCHK(hipSetDevice(g->device));
     const long N = g->N;
@@ -1094,6 +1200,7 @@ int gp_kernel_matrix(gp_t *g, double *K) {
 // ---- candidates / predict -----------------------------------------------------------------------
 int gp_set_candidates(gp_t *g, const double *Xs, int64_t M) {
     if (!g || !Xs) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->have_data) return fail(GP_ERR_STATE, "gp_set_data first");
     if (M < 1) return fail(GP_ERR_ARG, "M < 1");
     HIPCHK(hipSetDevice(g->device));
@@ -1153,6 +1260,7 @@ static int ensure_out(gp_ctx *g) {
 
 int gp_predict(gp_t *g, int include_noise, double *mean, double *var) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     HIPCHK(hipSetDevice(g->device));
@@ -1167,6 +1275,7 @@ int gp_predict(gp_t *g, int include_noise, double *mean, double *var) {
 
 int gp_fmin(gp_t *g, double *fmin) {
     if (!g || !fmin) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->P != 1) return fail(GP_ERR_ARG, "gp_fmin needs P == 1");
     HIPCHK(hipSetDevice(g->device));
@@ -1199,6 +1308,7 @@ static int run_acq(gp_ctx *g, int type, double par, double fmin, double y_mean, 
 
 int gp_acq(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, double *out) {
     if (!g || !out) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     HIPCHK(hipSetDevice(g->device));
@@ -1212,6 +1322,7 @@ int gp_acq(gp_t *g, int type, double par, double fmin, double y_mean, double y_s
 int gp_acq_argbest(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, int sense, int64_t *idx,
                    double *val) {
     if (!g || !idx || !val) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     if (sense != 1 && sense != -1) return fail(GP_ERR_ARG, "sense must be +1 or -1");
@@ -1251,6 +1362,7 @@ static int run_acq_lp(gp_ctx *g, int type, double par, double fmin, double y_mea
 int gp_acq_lp(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, int transform,
               const double *Xb, int nb, const double *r_x0, const double *s_x0, double *out) {
     if (!g || !out || (nb > 0 && (!Xb || !r_x0 || !s_x0))) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     HIPCHK(hipSetDevice(g->device));
@@ -1266,6 +1378,7 @@ int gp_acq_lp_argbest(gp_t *g, int type, double par, double fmin, double y_mean,
                       const int64_t *exclude, int nex, int64_t *idx, double *val) {
     if (!g || !idx || !val || (nb > 0 && (!Xb || !r_x0 || !s_x0)) || (nex > 0 && !exclude))
         return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     if (sense != 1 && sense != -1) return fail(GP_ERR_ARG, "sense must be +1 or -1");
@@ -1293,6 +1406,7 @@ int gp_acq_lp_argbest(gp_t *g, int type, double par, double fmin, double y_mean,
 // ---- measurement ----------------------------------------------------------------------------------
 int gp_last_phases(gp_t *g, int cap, const char **names, double *ms, double *flops, double *bytes) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     hipSetDevice(g->device);
     hipStreamSynchronize(g->s);
     int n = std::min(cap, g->nphases);
@@ -1309,6 +1423,7 @@ int gp_last_phases(gp_t *g, int cap, const char **names, double *ms, double *flo
 
 int gp_profile(gp_t *g, int on) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     g->profiling = on != 0;
     g->gemm_ev_used = 0;
     g->gemm_tiles.clear();
@@ -1321,6 +1436,7 @@ int gp_profile(gp_t *g, int on) {
 
 int gp_gemm_stats(gp_t *g, int64_t *launches, double *ms, double *flops) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     hipSetDevice(g->device);
     hipStreamSynchronize(g->s_panel);
     if (g->s_bulk) hipStreamSynchronize(g->s_bulk);
@@ -1343,6 +1459,7 @@ int gp_gemm_stats(gp_t *g, int64_t *launches, double *ms, double *flops) {
 // durations counts shared time twice; flops / busy is the kernel's throughput while it runs.
 int gp_gemm_busy(gp_t *g, double *busy_ms) {
     if (!g || !busy_ms) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     hipSetDevice(g->device);
     hipStreamSynchronize(g->s_panel);
     if (g->s_bulk) hipStreamSynchronize(g->s_bulk);
@@ -1374,6 +1491,7 @@ int gp_gemm_busy(gp_t *g, double *busy_ms) {
 
 int gp_gemm_trace(gp_t *g, int cap, int64_t *tiles, int *K, double *ms) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     hipSetDevice(g->device);
     hipStreamSynchronize(g->s_panel);
     if (g->s_bulk) hipStreamSynchronize(g->s_bulk);
@@ -1403,6 +1521,7 @@ int gp_comm_unique_id(char *uid128) {
 
 int gp_comm_init(gp_t *g, const char *uid128, int rank, int nranks) {
     if (!g || !uid128) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(GP_ERR_ARG, "bad rank %d / %d", rank, nranks);
     HIPCHK(hipSetDevice(g->device));
     if (g->comm) {
@@ -1431,6 +1550,7 @@ int gp_comm_destroy(gp_t *g) {
 
 int gp_comm_allgather_best(gp_t *g, double val, int64_t idx, double *vals, int64_t *idxs) {
     if (!g || !vals || !idxs) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->comm) return fail(GP_ERR_STATE, "gp_comm_init first");
     if (g->nranks > 128) return fail(GP_ERR_ARG, "nranks > 128");
     HIPCHK(hipSetDevice(g->device));
@@ -1455,16 +1575,29 @@ int gp_comm_allgather_best(gp_t *g, double val, int64_t idx, double *vals, int64
 
 int gp_comm_bcast_fit(gp_t *g, int root) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->comm) return fail(GP_ERR_STATE, "gp_comm_init first");
     if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "every rank needs data and params set");
     HIPCHK(hipSetDevice(g->device));
+    if (root < 0 || root >= g->nranks) return fail(GP_ERR_ARG, "root %d out of range", root);
+    if (g->rank == root && !g->fitted) return fail(GP_ERR_STATE, "the root rank must be fitted");
     const long Npad = g->Npad;
+    // host-side fit state rides along as a small record: a receiver's gp_fmin uses the root's jitter
+    // (y - (noise + 1e-8 + jitter) alpha) and reports the root's LML / log det
+    double rec[4] = {g->jitter, g->lml, g->logdet, 0.0};
+    double *dRec = g->dScal + 400;
+    if (g->rank == root) HIPCHK(hipMemcpyAsync(dRec, rec, sizeof rec, hipMemcpyHostToDevice, g->s));
     NCCLCHK(ncclGroupStart());
     NCCLCHK(ncclBroadcast(g->dA, g->dA, (size_t)(Npad + GP_MAX_RHS) * Npad, ncclDouble, root, g->comm, g->s));
     NCCLCHK(ncclBroadcast(g->dInvL, g->dInvL, (size_t)Npad * GP_TILE, ncclDouble, root, g->comm, g->s));
     NCCLCHK(ncclBroadcast(g->dAlpha, g->dAlpha, (size_t)Npad * g->P, ncclDouble, root, g->comm, g->s));
+    NCCLCHK(ncclBroadcast(dRec, dRec, 4, ncclDouble, root, g->comm, g->s));
     NCCLCHK(ncclGroupEnd());
+    HIPCHK(hipMemcpyAsync(rec, dRec, sizeof rec, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipStreamSynchronize(g->s));
+    g->jitter = rec[0];
+    g->lml = rec[1];
+    g->logdet = rec[2];
     g->fitted = true;
     g->fmin_valid = false;
     g->wi_valid = false;
@@ -1537,6 +1670,7 @@ static int ensure_wi(gp_ctx *g) {
 
 int gp_get_woodbury_inv(gp_t *g, double *Wi) {
     if (!g || !Wi) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     HIPCHK(hipSetDevice(g->device));
     int rc;
     if ((rc = ensure_wi(g))) return rc;
@@ -1548,6 +1682,7 @@ int gp_get_woodbury_inv(gp_t *g, double *Wi) {
 
 static int lml_grad_impl(gp_ctx *g, double *dvariance, double *dlengthscale, double *dnoise, bool reset_phases) {
     if (!g || !dvariance || !dlengthscale || !dnoise) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
     if (g->kp.gower) return fail(GP_ERR_STATE, "hyper-gradients of the Gower kernel are not replicated (the fork mixes "
@@ -1596,6 +1731,7 @@ int gp_lml_grad(gp_t *g, double *dvariance, double *dlengthscale, double *dnoise
 int gp_fit_grad(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_used, double *dvariance,
                 double *dlengthscale, double *dnoise) {
     if (!g || !dvariance || !dlengthscale || !dnoise) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit_grad");
     if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
     if (g->kp.gower) return fail(GP_ERR_STATE, "hyper-gradients of the Gower kernel are not replicated (the fork mixes "
@@ -1657,6 +1793,7 @@ static int run_predict_grad(gp_ctx *g) {
 
 int gp_predict_grad(gp_t *g, double *dmdx, double *dvdx) {
     if (!g || !dmdx || !dvdx) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     HIPCHK(hipSetDevice(g->device));
     int rc;
     if ((rc = run_predict_grad(g))) return rc;
@@ -1668,6 +1805,7 @@ int gp_predict_grad(gp_t *g, double *dmdx, double *dvdx) {
 
 int gp_acq_grad(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, double *out, double *dout) {
     if (!g || !out || !dout) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     if (g->P != 1) return fail(GP_ERR_ARG, "acquisitions need P == 1");
@@ -1688,6 +1826,7 @@ int gp_acq_grad(gp_t *g, int type, double par, double fmin, double y_mean, doubl
 // full_cov = True branch of PosteriorExact._raw_predict (posterior.py:280-284)
 int gp_predict_full_cov(gp_t *g, int include_noise, double *mean, double *cov) {
     if (!g || !cov) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     HIPCHK(hipSetDevice(g->device));
@@ -1705,6 +1844,164 @@ int gp_predict_full_cov(gp_t *g, int include_noise, double *mean, double *cov) {
     HIPCHK(hipStreamSynchronize(g->s));
     HIPCHK(hipMemcpy2D(cov, sizeof(double) * M, g->dCov, sizeof(double) * Mpad, sizeof(double) * M, M,
                        hipMemcpyDeviceToHost));
+    return 0;
+}
+
+
+/* ---- fit state (host scalars of the last fit, also what gp_comm_bcast_fit delivers to the receivers) ---- */
+int gp_get_fit_state(gp_t *g, double *lml, double *logdet, double *jitter) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (lml) *lml = g->lml;
+    if (logdet) *logdet = g->logdet;
+    if (jitter) *jitter = g->jitter;
+    return 0;
+}
+
+// ---- top-k of the acquisition scores (anchor_points_generator.py:61: argsort(scores)[:num_anchor]) ---------------
+// k rounds of the deterministic arg-best reduction, each followed by masking the winner on the device: ties resolve
+// to the lowest index in every round, i.e. the order of a stable sort by (score, index).
+int gp_acq_topk(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, int sense, int k,
+                int64_t *idx, double *val) {
+    if (!g || !idx || !val) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    if (sense != 1 && sense != -1) return fail(GP_ERR_ARG, "sense must be +1 or -1");
+    if (k < 1 || k > GP_TOPK_MAX) return fail(GP_ERR_ARG, "k out of range (1..%d)", GP_TOPK_MAX);
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = run_acq(g, type, par, fmin, y_mean, y_std))) return rc;
+    if ((rc = dev_realloc(&g->dComm, &g->capComm, 2L * GP_TOPK_MAX * (1 + 128)))) return rc;
+    double *dv = g->dComm;
+    long long *di = (long long *)(g->dComm + GP_TOPK_MAX);
+    const int kk = (int)std::min<long>(k, g->M);
+    for (int j = 0; j < kk; ++j) {
+        launch_argbest(g->s, g->dAcq, g->M, sense, g->dRedV + 256, g->dRedI + 256, g->dRedV, g->dRedI);
+        HIPCHK(hipMemcpyAsync(dv + j, g->dRedV + 256, 8, hipMemcpyDeviceToDevice, g->s));
+        HIPCHK(hipMemcpyAsync(di + j, g->dRedI + 256, 8, hipMemcpyDeviceToDevice, g->s));
+        launch_mask(g->s, g->dAcq, g->dRedI + 256, 1, sense > 0 ? -INFINITY : INFINITY);
+    }
+    std::vector<long long> hi(kk);
+    HIPCHK(hipMemcpyAsync(val, dv, sizeof(double) * kk, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipMemcpyAsync(hi.data(), di, sizeof(long long) * kk, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    for (int j = 0; j < kk; ++j) idx[j] = (int64_t)hi[j];
+    for (int j = kk; j < k; ++j) {  // fewer candidates than k: the tail is marked empty
+        idx[j] = -1;
+        val[j] = sense > 0 ? -INFINITY : INFINITY;
+    }
+    return 0;
+}
+
+int gp_comm_allgather_topk(gp_t *g, int k, const double *vals, const int64_t *idxs, double *all_vals,
+                           int64_t *all_idxs) {
+    if (!g || !vals || !idxs || !all_vals || !all_idxs) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
+    if (!g->comm) return fail(GP_ERR_STATE, "gp_comm_init first");
+    if (k < 1 || k > GP_TOPK_MAX) return fail(GP_ERR_ARG, "k out of range (1..%d)", GP_TOPK_MAX);
+    if (g->nranks > 128) return fail(GP_ERR_ARG, "nranks > 128");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = dev_realloc(&g->dComm, &g->capComm, 2L * GP_TOPK_MAX * (1 + 128)))) return rc;
+    // k records of {double val, int64 idx} per rank, moved as 2k x 8 bytes
+    std::vector<double> rec(2 * (size_t)k);
+    for (int j = 0; j < k; ++j) {
+        rec[2 * j] = vals[j];
+        memcpy(&rec[2 * j + 1], &idxs[j], 8);
+    }
+    double *send = g->dComm, *recv = g->dComm + 2 * GP_TOPK_MAX;
+    HIPCHK(hipMemcpyAsync(send, rec.data(), 16 * (size_t)k, hipMemcpyHostToDevice, g->s));
+    NCCLCHK(ncclAllGather(send, recv, 2 * (size_t)k, ncclDouble, g->comm, g->s));
+    std::vector<double> out(2 * (size_t)k * g->nranks);
+    HIPCHK(hipMemcpyAsync(out.data(), recv, 16 * (size_t)k * g->nranks, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    for (size_t r = 0; r < (size_t)k * g->nranks; ++r) {
+        all_vals[r] = out[2 * r];
+        memcpy(&all_idxs[r], &out[2 * r + 1], 8);
+    }
+    return 0;
+}
+
+// ---- dL_dK = 0.5 (alpha alpha^T - P Ky^-1)  (exact_gaussian_inference.py:70) -------------------------------
+// What grad_dict['dL_dK'] carries into kern.update_gradients_full (gp.py:269) when the reference's own kernel classes
+// consume it on the host.  gp_lml_grad forms the same matrix implicitly inside its fused reduction.
+int gp_get_dl_dk(gp_t *g, double *dL_dK) {
+    if (!g || !dL_dK) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = ensure_wi(g))) return rc;  // leaves dT free (Npad x Npad)
+    const long N = g->N, Npad = g->Npad;
+    launch_dldk(g->s, g->dT, Npad, g->dAlpha, Npad, g->P, g->dWi, Npad, N);
+    HIPCHK(hipStreamSynchronize(g->s));
+    HIPCHK(hipMemcpy2D(dL_dK, sizeof(double) * N, g->dT, sizeof(double) * Npad, sizeof(double) * N, N,
+                       hipMemcpyDeviceToHost));
+    g->predicted = false;  // dT was reused
+    return 0;
+}
+
+// ---- posterior samples of the latent function (GP.posterior_samples_f, gp.py:581-609) ------------------------
+// dev[s, :] = C z_s with C C^T = cov(Xs) (+ noise I) the full posterior covariance (posterior.py:280-284) of the resident
+// candidates and z_s the caller's standard normals: the M x M Cholesky runs on the device with the same tile kernels as
+// the fit, under GPy's jitter ladder (jitchol, linalg.py:56-81).  mean[M,P] is returned beside the deviations; a sample
+// of output d is mean[:, d] + dev[s, :].  (The reference draws through numpy's multivariate_normal, whose SVD factor
+// differs from C by an orthogonal matrix: same distribution, different draws for the same generator state.)
+int gp_posterior_samples(gp_t *g, int include_noise, const double *Z, int S, int maxtries, double *mean, double *dev,
+                         double *jitter_used) {
+    if (!g || !Z || !dev) return fail(GP_ERR_ARG, "null argument");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    if (S < 1) return fail(GP_ERR_ARG, "S < 1");
+    HIPCHK(hipSetDevice(g->device));
+    const long M = g->M, Npad = g->Npad, Mpad = round_up(M, GP_TILE), Spad = round_up(S, GP_TILE);
+    if (Mpad > g->mc_max) return fail(GP_ERR_ARG, "posterior samples need M <= mc_max (%ld)", g->mc_max);
+    int rc;
+    if ((rc = ensure_out(g))) return rc;
+    if ((rc = run_predict(g, include_noise))) return rc;  // S_c = K(Xs,X) L^-T in dT2 (single chunk), mean in dMean
+    // dCov: [cov Mpad x Mpad][Z^T Spad x Mpad][dev Spad x Mpad]; the inverted diagonal tiles go to dT (free now)
+    if ((rc = dev_realloc(&g->dCov, &g->capCov, std::max(g->capCov, Mpad * Mpad + 2 * Spad * Mpad)))) return rc;
+    double *C = g->dCov, *Zd = g->dCov + Mpad * Mpad, *Dv = Zd + Spad * Mpad;
+    double *invL = g->dT;
+    const int mt = (int)(Mpad / GP_TILE), st = (int)(Spad / GP_TILE);
+    HIPCHK(hipMemsetAsync(Zd, 0, sizeof(double) * Spad * Mpad, g->s));
+    HIPCHK(hipMemcpy2DAsync(Zd, sizeof(double) * Mpad, Z, sizeof(double) * M, sizeof(double) * M, S,
+                            hipMemcpyHostToDevice, g->s));
+    const double diag0 = (g->kp.gower ? std::pow(g->kp.variance, g->D) : g->kp.variance) + (include_noise ? g->noise : 0.0);
+    double jitter = 0.0;
+    int tries = 0, info = 0;
+    for (;;) {
+        launch_kbuild(g->s, C, Mpad, g->dXs, M, Mpad, g->kp, 0.0, 1);  // K(Xs, Xs), identity on the padding rows
+        gemm(g, g->s, 1, C, Mpad, g->dT2, Npad, g->dT2, Npad, 1, (int)Npad, TileSet{0, mt, 0, mt, 0});
+        if (include_noise) launch_add_diag(g->s, C, Mpad, M, g->noise);
+        if (jitter != 0.0) launch_add_diag(g->s, C, Mpad, M, jitter);
+        HIPCHK(hipMemsetAsync(g->dInfo, 0, sizeof(int) * 4, g->s));
+        factor_buf(g, C, Mpad, mt, mt, invL, g->dInfo);
+        HIPCHK(hipMemcpyAsync(&info, g->dInfo, sizeof(int), hipMemcpyDeviceToHost, g->s));
+        HIPCHK(hipStreamSynchronize(g->s));
+        if (info == 0) break;
+        // jitchol: mean(diag) * 1e-6 * 10^k (linalg.py:62-75); the posterior covariance's diagonal is bounded by diag0
+        if (!(diag0 > 0.0)) return fail(GP_ERR_NOT_PD_DIAG, "not pd: non-positive diagonal elements");
+        jitter = tries == 0 ? diag0 * 1e-6 : jitter * 10.0;
+        if (++tries > maxtries || !std::isfinite(jitter)) {
+            g_err = "not positive definite, even with jitter.";
+            return info > 0 ? info : 1;
+        }
+    }
+    launch_zero_upper_diag(g->s, C, Mpad, mt);
+    // dev[s, m] = sum_{k <= m} z[s, k] C[m, k]: B = the factor's rows, contraction ends at the diagonal tile
+    GemmOpt o;
+    o.k_end_tri = 1;
+    gemm(g, g->s, 0, Dv, Mpad, Zd, Mpad, C, Mpad, 1, (int)Mpad, TileSet{0, st, 0, mt, 0}, o);
+    if (mean) HIPCHK(hipMemcpyAsync(mean, g->dMean, sizeof(double) * M * g->P, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipMemcpy2DAsync(dev, sizeof(double) * M, Dv, sizeof(double) * Mpad, sizeof(double) * M, S,
+                            hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    if (jitter_used) *jitter_used = jitter;
+    g->predicted = false;  // dT was used as workspace
     return 0;
 }
 

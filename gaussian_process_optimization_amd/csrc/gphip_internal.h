@@ -131,3 +131,8 @@ void launch_transpose_blocks(hipStream_t s, double *dst, const double *src, long
 void launch_lp(hipStream_t s, const double *negacq, const double *Xs, long M, int D, const double *Xb, int nb,
                const double *r0, const double *s0, int transform, double *out);
 void launch_mask(hipStream_t s, double *v, const long long *idx, int n, double fill);
+// out[i, j] = 0.5 (sum_p alpha_p[i] alpha_p[j] - P Wi[i, j]),  i, j < N  (exact_gaussian_inference.py:70)
+void launch_dldk(hipStream_t s, double *out, long ldo, const double *alpha, long lda_, int P, const double *Wi,
+                 long ldw, long N);
+// zero the strict upper triangle of the nt diagonal 128-tiles (the factor's tiles keep the symmetric input there)
+void launch_zero_upper_diag(hipStream_t s, double *A, long lda, int nt);

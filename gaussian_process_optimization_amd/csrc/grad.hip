@@ -439,3 +439,28 @@ __global__ void mask_kernel(double *v, const long long *idx, int n, double fill)
 void launch_mask(hipStream_t s, double *v, const long long *idx, int n, double fill) {
     if (n > 0) hipLaunchKernelGGL(mask_kernel, dim3(1), dim3(256), 0, s, v, idx, n, fill);
 }
+
+__global__ __launch_bounds__(256) void dldk_kernel(double *out, long ldo, const double *alpha, long lda_, int P,
+                                                   const double *Wi, long ldw, long N) {
+    const long j = blockIdx.x * 256L + threadIdx.x, i = blockIdx.y;
+    if (j >= N) return;
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s = fma(alpha[p * lda_ + i], alpha[p * lda_ + j], s);
+    out[i * ldo + j] = 0.5 * (s - (double)P * Wi[i * ldw + j]);
+}
+void launch_dldk(hipStream_t s, double *out, long ldo, const double *alpha, long lda_, int P, const double *Wi,
+                 long ldw, long N) {
+    hipLaunchKernelGGL(dldk_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, s, out, ldo, alpha,
+                       lda_, P, Wi, ldw, N);
+}
+
+__global__ __launch_bounds__(256) void zero_upper_diag_kernel(double *A, long lda) {
+    double *At = A + (long)blockIdx.x * GP_TILE * lda + (long)blockIdx.x * GP_TILE;
+    for (int id = threadIdx.x; id < GP_TILE * GP_TILE; id += 256) {
+        const int r = id >> 7, c = id & 127;
+        if (c > r) At[(long)r * lda + c] = 0.0;
+    }
+}
+void launch_zero_upper_diag(hipStream_t s, double *A, long lda, int nt) {
+    hipLaunchKernelGGL(zero_upper_diag_kernel, dim3((unsigned)nt), dim3(256), 0, s, A, lda);
+}

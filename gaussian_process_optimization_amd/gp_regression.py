@@ -291,14 +291,28 @@ class GPRegression(Parameterized):
         _, C = self._raw_predict(np.vstack([X1, X2]), full_cov=True)
         return C[:X1.shape[0], X1.shape[0]:]
 
-    def posterior_samples_f(self, X, size=10, **kw):
-        """gp.py:581-609 (host-side draw from the device-computed full covariance)."""
-        m, v = self._raw_predict(X, full_cov=True)
+    def posterior_samples_f(self, X, size=10, normals=None, **kw):
+        """gp.py:581-609: draws of the latent function at X, [Nnew, output_dim, size].
+
+        The Nnew x Nnew posterior covariance (posterior.py:280-284) is built and Cholesky-factored on the device
+        (gp_posterior_samples, GPy's jitter ladder) and applied to standard normals: ``normals`` [output_dim, size,
+        Nnew] if given (reproducible draws), else ``np.random.standard_normal`` -- the global generator the
+        reference's ``np.random.multivariate_normal`` consumes too (its SVD factor gives other draws of the same law)."""
+        X = np.atleast_2d(np.asarray(X, dtype=float))
+        M, P = X.shape[0], self.output_dim
+        if normals is None:
+            normals = np.random.standard_normal((P, size, M))
+        normals = np.asarray(normals, dtype=float).reshape(P, size, M)
+        self._stage(X)
+        m, dev, _ = self._h.posterior_samples(normals.reshape(P * size, M), include_noise=False)
+        dev = dev.reshape(P, size, M)
         if self.normalizer is not None:
-            m, v = self.normalizer.inverse_mean(m), self.normalizer.inverse_variance(v)
-        fsim = np.empty((X.shape[0], self.output_dim, size))
-        for d in range(self.output_dim):
-            fsim[:, d, :] = np.random.multivariate_normal(m[:, d], v, size).T
+            # inverse_mean / inverse_variance (normalizer.py:85-108): deviations scale with std, like sqrt(variance)
+            m = self.normalizer.inverse_mean(m)
+            dev = dev * np.asarray(self.normalizer.std, dtype=float).reshape(-1, 1, 1)
+        fsim = np.empty((M, P, size))
+        for d in range(P):
+            fsim[:, d, :] = m[:, d:d + 1] + dev[d].T
         return fsim
 
     # -- optimisation -------------------------------------------------------------------
@@ -311,21 +325,19 @@ class GPRegression(Parameterized):
             if not self._uses_gower():
                 g = self.objective_function_gradients()   # gp_fit_grad: leaves the LML of this x behind
                 return self.objective_function(), g
+            # Gower kernel: the fork pairs the Gower K with Euclidean gradient formulas (stationary.py:218-238), which
+            # are not gradients of this objective; forward differences of the device LML are used instead
             f = self.objective_function()
-            if True:  # Gower kernel
-                # the fork pairs the Gower K with Euclidean gradient formulas (stationary.py:218-238), which are not
-                # gradients of this objective; forward differences of the device LML are used instead
-                g = np.empty_like(x)
-                for i in range(x.size):
-                    e = np.zeros_like(x)
-                    e[i] = 1e-6
-                    self.optimizer_array = x + e
-                    g[i] = (self.objective_function() - f) / 1e-6
-                self.optimizer_array = x
-                return f, g
+            g = np.empty_like(x)
+            for i in range(x.size):
+                e = np.zeros_like(x)
+                e[i] = 1e-6
+                self.optimizer_array = x + e
+                g[i] = (self.objective_function() - f) / 1e-6
+            self.optimizer_array = x
+            return f, g
         except np.linalg.LinAlgError:
             return 1e10, np.zeros_like(x)  # paramz Model._objective_grads: failed evaluations are walls
-        return f, g
 
     def optimize(self, optimizer=None, start=None, messages=False, max_iters=1000, ipython_notebook=False,
                  clear_after_finish=False, **kwargs):
@@ -335,7 +347,7 @@ class GPRegression(Parameterized):
         x0 = self.optimizer_array if start is None else np.asarray(start, dtype=float)
         if x0.size == 0:
             return None
-        res = _sopt.fmin_l_bfgs_b(self._obj_grad, x0, maxiter=int(max_iters), maxfun=int(max_iters) * 2)
+        res = _sopt.fmin_l_bfgs_b(self._obj_grad, x0, maxiter=int(max_iters), maxfun=int(max_iters))
         xbest = res[0]
         self.optimizer_array = xbest
         self._ensure_fit()

@@ -38,6 +38,19 @@ def merge_best(vals, idxs, sense):
     return int(i[v == best].min()), float(best)
 
 
+def merge_topk(vals, idxs, k, sense):
+    """The k best of the gathered per-rank (value, global index) pairs, in order; equal values -> lowest global
+    index first (the order ``np.argsort(scores, kind="stable")[:k]`` gives on the unsharded table,
+    anchor_points_generator.py:61).  Pairs with idx < 0 (empty slots) are ignored.  Returns (indices[k'], values[k'])
+    with k' = min(k, number of valid pairs)."""
+    vals = np.asarray(vals, dtype=float).reshape(-1)
+    idxs = np.asarray(idxs, dtype=np.int64).reshape(-1)
+    ok = idxs >= 0
+    v, i = vals[ok], idxs[ok]
+    order = np.lexsort((i, v if sense < 0 else -v))[:k]
+    return i[order], v[order]
+
+
 class RcclCollective(object):
     """All-gather of (val, idx) through libgphip's RCCL communicator (GPU ranks)."""
 
@@ -46,6 +59,9 @@ class RcclCollective(object):
 
     def allgather_best(self, val, idx):
         return self.h.comm_allgather_best(val, idx, self.nranks)
+
+    def allgather_topk(self, vals, idxs):
+        return self.h.comm_allgather_topk(vals, idxs, self.nranks)
 
 
 class TorchCollective(object):
@@ -64,6 +80,17 @@ class TorchCollective(object):
         dist.all_gather(vs, v)
         dist.all_gather(is_, i)
         return np.array([t.item() for t in vs]), np.array([t.item() for t in is_], dtype=np.int64)
+
+    def allgather_topk(self, vals, idxs):
+        import torch
+        import torch.distributed as dist
+        v = torch.tensor(np.asarray(vals, dtype=float))
+        i = torch.tensor(np.asarray(idxs, dtype=np.int64))
+        vs = [torch.zeros_like(v) for _ in range(self.nranks)]
+        is_ = [torch.zeros_like(i) for _ in range(self.nranks)]
+        dist.all_gather(vs, v)
+        dist.all_gather(is_, i)
+        return torch.cat(vs).numpy(), torch.cat(is_).numpy()
 
 
 class ShardedCandidates(object):
@@ -85,3 +112,19 @@ class ShardedCandidates(object):
             gi, val = -1, (-np.inf if sense > 0 else np.inf)
         vals, idxs = self.collective.allgather_best(val, gi)
         return merge_best(vals, idxs, sense)
+
+    def topk(self, X_all, score_local_topk, k, sense=-1):
+        """The k best rows of the whole table: every rank contributes the k best of its block
+        (``score_local_topk(Xblock, k, sense) -> (local indices[k], values[k])``, -1 marking empty slots:
+        ``Acquisition*.topk`` on the HIP path), ONE all-gather of ``nranks * k`` pairs, then the same merge on every
+        rank (the "gather 8 x k pairs" variant of anchor_points_generator.py:61)."""
+        lo, hi = shard_bounds(X_all.shape[0], self.rank, self.nranks)
+        li = np.full(k, -1, dtype=np.int64)
+        lv = np.full(k, np.inf if sense < 0 else -np.inf)
+        if hi > lo:
+            i, v = score_local_topk(X_all[lo:hi], k, sense)
+            i = np.asarray(i, dtype=np.int64)
+            li[:i.size] = np.where(i >= 0, lo + i, -1)
+            lv[:i.size] = v
+        vals, idxs = self.collective.allgather_topk(lv, li)
+        return merge_topk(vals, idxs, k, sense)

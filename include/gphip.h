@@ -43,6 +43,8 @@ typedef struct gp_ctx gp_t;
 #define GP_ERR_RCCL (-4)
 #define GP_ERR_NOT_PD_DIAG (-5) /* "not pd: non-positive diagonal elements", linalg.py:63-64 */
 
+#define GP_TOPK_MAX 64 /* largest k of gp_acq_topk / gp_comm_allgather_topk */
+
 /* ---- library / device -------------------------------------------------- */
 const char *gp_last_error(void);
 const char *gp_version(void);
@@ -55,6 +57,12 @@ int gp_device_info(int device, char *name, int cap, int *cus, int64_t *hbm_bytes
  * GPy/GPy/core/gp.py:38-110): an empty model bound to one device. */
 int gp_create(gp_t **out, int device);
 int gp_destroy(gp_t *gp);
+/* Ordered library shutdown: waits for every device the library used, destroys the events of the live contexts and then
+ * the per-device stream set (which otherwise lives for the whole process: hardware queues keep their command-processor
+ * pipe only while they are never re-created).  Registered with atexit() at the first gp_create, so a process that
+ * simply exits -- also under rocprofv3 -- tears the queues down before the HIP runtime's own exit handlers run.
+ * Contexts still alive afterwards only accept gp_destroy. */
+int gp_shutdown(void);
 
 /* GP.set_XY (GPy/GPy/core/gp.py:202-238): X[N,D], Y[N,P] row-major, copied H2D. 1 <= P <= 128. */
 int gp_set_data(gp_t *gp, const double *X, const double *Y, int64_t N, int D, int P);
@@ -79,6 +87,8 @@ int gp_set_gower(gp_t *gp, int enable, const int *is_discrete, const double *ran
  * Outputs: *lml, *logdet, *jitter_used (0 when the first dpotrf succeeds). */
 int gp_fit(gp_t *gp, int maxtries, double *lml, double *logdet, double *jitter_used);
 
+/* lml / logdet / jitter of the last fit (or of the root's fit after gp_comm_bcast_fit). */
+int gp_get_fit_state(gp_t *gp, double *lml, double *logdet, double *jitter);
 /* Posterior.woodbury_vector (posterior.py:198-214): alpha[N,P]. */
 int gp_get_alpha(gp_t *gp, double *alpha);
 /* Posterior.woodbury_chol: L[N,N] row-major, lower triangle (upper written as 0). */
@@ -94,6 +104,12 @@ int gp_kernel_matrix(gp_t *gp, double *K);
  *   dvariance, dlengthscale[1 or D] = Stationary.update_gradients_full (stationary.py:218-238).
  * Natural-space gradients of the LML; the Logexp chain rule stays on the host. Requires gp_fit. */
 int gp_lml_grad(gp_t *gp, double *dvariance, double *dlengthscale, double *dnoise);
+
+/* grad_dict['dL_dK'] of ExactGaussianInference.inference (exact_gaussian_inference.py:70,74):
+ *   dL_dK[N,N] = 0.5 (alpha alpha^T - P Ky^-1), the matrix GP.parameters_changed hands to
+ *   kern.update_gradients_full (gp.py:269) -- for reference-side kernels that reduce it on the host.
+ *   (gp_lml_grad reduces the same matrix on the device without materialising it.)  Requires gp_fit. */
+int gp_get_dl_dk(gp_t *gp, double *dL_dK);
 
 /* gp_fit + gp_lml_grad as ONE call -- what every L-BFGS evaluation of the hyper-parameter loop asks for
  * (Model.objective_function + objective_function_gradients, GPy/GPy/core/model.py:96-127; GPyOpt
@@ -122,6 +138,14 @@ int gp_fit_predict(gp_t *gp, int maxtries, int include_noise, double *lml, doubl
 /* full_cov = True branch (posterior.py:280-284): cov[M,M] = K(Xs) - tmp^T tmp (+ noise I). */
 int gp_predict_full_cov(gp_t *gp, int include_noise, double *mean, double *cov);
 
+/* GP.posterior_samples_f (gp.py:581-609) on the resident candidates: the full posterior covariance
+ * (posterior.py:280-284, + noise I when include_noise) is factored on the device, C C^T = cov, under GPy's jitter
+ * ladder (jitchol, linalg.py:56-81; maxtries as there), and applied to the caller's standard normals Z[S,M]:
+ *   dev[S,M] = (C z_s)^T;  a draw of output d is mean[:,d] + dev[s,:].  mean[M,P] may be NULL.
+ * M <= "mc_max".  Return codes as gp_fit (k > 0: not positive definite even with jitter). */
+int gp_posterior_samples(gp_t *gp, int include_noise, const double *Z, int S, int maxtries, double *mean, double *dev,
+                         double *jitter_used);
+
 /* GP.predictive_gradients (gp.py:407-454): dmdx[M,D,P], dvdx[M,D]. */
 int gp_predict_grad(gp_t *gp, double *dmdx, double *dvdx);
 
@@ -144,6 +168,12 @@ int gp_acq(gp_t *gp, int type, double par, double fmin, double y_mean, double y_
  * candidate set. */
 int gp_acq_argbest(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std,
                    int sense, int64_t *idx, double *val);
+
+/* The k best scores in order (AnchorPointsGenerator.get, GPyOpt/GPyOpt/optimization/anchor_points_generator.py:59-61:
+ * argsort(scores)[:num_anchor]): idx[k], val[k]; equal scores come out lowest index first; when M < k the tail is
+ * idx = -1.  1 <= k <= GP_TOPK_MAX. */
+int gp_acq_topk(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std, int sense, int k,
+                int64_t *idx, double *val);
 
 /* acquisition_function_withGradients (base.py:42-50; EI.py:42-51, LCB.py:39-46, MPI.py:42-51):
  * out[M] negated value, dout[M,D] negated gradient. */
@@ -172,7 +202,12 @@ int gp_comm_init(gp_t *gp, const char *uid128, int rank, int nranks);
 int gp_comm_destroy(gp_t *gp);
 /* all-gather of one (val, idx) pair per rank: vals[nranks], idxs[nranks]. */
 int gp_comm_allgather_best(gp_t *gp, double val, int64_t idx, double *vals, int64_t *idxs);
-/* broadcast of a fitted model's factor from root to all ranks (L, alpha, z, inverse tiles). */
+/* the top-k variant ("gather 8 x k pairs"): every rank contributes its k best (val, global idx) pairs
+ * (idx < 0 marks an empty slot); all_vals / all_idxs [nranks * k], rank-major. */
+int gp_comm_allgather_topk(gp_t *gp, int k, const double *vals, const int64_t *idxs, double *all_vals,
+                           int64_t *all_idxs);
+/* broadcast of a fitted model from root to all ranks: L, alpha, z, inverse tiles and the host-side scalars of the fit
+ * (jitter, LML, log det), so that gp_fmin and gp_get_fit_state agree on every rank. */
 int gp_comm_bcast_fit(gp_t *gp, int root);
 
 /* ---- measurement ---------------------------------------------------------

@@ -704,3 +704,56 @@ def lp_d_acquisition(neg_acq, neg_dacq, x, X_batch, r_x0, s_x0, transform="none"
     d = 1. / (s_x0 * np.sqrt(2 * np.pi) * h_func) * np.exp(-np.square(z) / 2) / nm
     d[h_func < 1e-50] = 0.
     return g - d[:, :, None].sum(axis=1)
+
+
+# ----------------------------------------------------------------------------
+# Local-penalisation evaluator (GPyOpt/GPyOpt/core/evaluators/batch_local_penalization.py)
+# ----------------------------------------------------------------------------
+def samples_multidimensional_uniform(bounds, num_data):
+    """GPyOpt/GPyOpt/util/general.py:63-73 (one np.random.uniform call per dimension, in this order)."""
+    dim = len(bounds)
+    Z_rand = np.zeros(shape=(num_data, dim))
+    for k in range(0, dim):
+        Z_rand[:, k] = np.random.uniform(low=bounds[k][0], high=bounds[k][1], size=num_data)
+    return Z_rand
+
+
+def estimate_L(model, bounds):
+    """batch_local_penalization.py:52-70: max over the box of |d mean / dx|, 500 uniform samples + the training
+    inputs as starting candidates, then L-BFGS-B from the best.  ``model`` is the GP (predictive_gradients, X)."""
+    import scipy.optimize
+
+    def df(x, model, x0):
+        x = np.atleast_2d(x)
+        dmdx, _ = model.predictive_gradients(x)
+        res = np.sqrt((dmdx * dmdx).sum(1))
+        return -res
+
+    samples = samples_multidimensional_uniform(bounds, 500)
+    samples = np.vstack([samples, model.X])
+    pred_samples = df(samples, model, 0)
+    x0 = samples[np.argmin(pred_samples)]
+    res = scipy.optimize.minimize(lambda x: float(np.ravel(df(x, model, x0))[0]), x0, method='L-BFGS-B',
+                                  bounds=bounds, options={'maxiter': 200})
+    L = -float(res.fun)
+    if L < 1e-7:
+        L = 10
+    return L
+
+
+def lp_compute_batch(acquisition, batch_size):
+    """LocalPenalization.compute_batch, batch_local_penalization.py:22-49; ``acquisition`` offers update_batches,
+    optimize, model.model (the GP) and space.get_bounds()."""
+    acquisition.update_batches(None, None, None)
+    X_batch = acquisition.optimize()[0]
+    k = 1
+    if batch_size > 1:
+        L = estimate_L(acquisition.model.model, acquisition.space.get_bounds())
+        Min = acquisition.model.model.Y.min()
+    while k < batch_size:
+        acquisition.update_batches(X_batch, L, Min)
+        new_sample = acquisition.optimize()[0]
+        X_batch = np.vstack((X_batch, new_sample))
+        k += 1
+    acquisition.update_batches(None, None, None)
+    return X_batch

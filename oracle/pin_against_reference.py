@@ -196,6 +196,130 @@ def check_invariants():
     return "reference test invariants (pinv form, var>=0, normaliser, checkgrad): hold"
 
 
+class _Space(object):
+    """The two methods of Design_space this path calls (space.py:303-318, 436-445), for a box without constraints."""
+
+    def __init__(self, bounds):
+        self._b = list(bounds)
+
+    def get_bounds(self):
+        return self._b
+
+    def indicator_constraints(self, x):
+        return np.ones((np.atleast_2d(x).shape[0], 1))
+
+
+def _oracle_model(kname="rbf", seed=3, noise=1e-2, N=80, D=2):
+    X, Y, Xs = O.synthetic_problem(N, D, 60, seed=seed)
+    gp = O.OracleGP(X, Y, O.make_kernel(kname, D, 1.3, O.default_lengthscale(D, False)), noise)
+    gm = O.OracleGPModel(gp)
+    gm.analytical_gradient_prediction = True   # BOModel flag read by AcquisitionBase.__init__ (base.py:22)
+    return gm, Xs
+
+
+def check_acquisitions(A):
+    """The reference's own AcquisitionEI / LCB / MPI / LP classes (verbatim modules) evaluated on an oracle-backed
+    model against the oracle's restatements: values, gradients and the negated acquisition_function."""
+    worst = 0.0
+    for kname in ("rbf", "Mat52"):
+        for noise in (1e-2, 1e-6):
+            gm, Xs = _oracle_model(kname, noise=noise)
+            space = _Space([(0.0, 1.0)] * Xs.shape[1])
+            fmin = gm.get_fmin()
+            cases = (
+                (A["EI"].AcquisitionEI(gm, space, None, None, jitter=0.01), O.acq_EI(gm, Xs, 0.01, fmin),
+                 O.acq_EI_withGradients(gm, Xs, 0.01, fmin)),
+                (A["LCB"].AcquisitionLCB(gm, space, None, None, exploration_weight=2), O.acq_LCB(gm, Xs, 2.0),
+                 O.acq_LCB_withGradients(gm, Xs, 2.0)),
+                (A["MPI"].AcquisitionMPI(gm, space, None, None, jitter=0.01), O.acq_MPI(gm, Xs, 0.01, fmin),
+                 O.acq_MPI_withGradients(gm, Xs, 0.01, fmin)),
+            )
+            for acq, f0, (f1, df1) in cases:
+                f = acq._compute_acq(Xs)
+                fg, dfg = acq._compute_acq_withGradients(Xs)
+                assert np.array_equal(f, f0) and np.array_equal(fg, f1) and np.array_equal(dfg, df1), type(acq).__name__
+                assert np.array_equal(acq.acquisition_function(Xs), O.acquisition_function(f0))
+                a, da = acq.acquisition_function_withGradients(Xs)
+                assert np.array_equal(a, O.acquisition_function(f1)) and np.array_equal(da, -df1)
+            # local penalisation around EI (transform 'none') and LCB (switches itself to 'softplus', LP.py:31-32)
+            Xb = Xs[:3]
+            for base, transform in ((cases[0][0], "none"), (cases[1][0], "softplus")):
+                lp = A["LP"].AcquisitionLP(gm, space, None, base, transform="none")
+                assert lp.transform == transform
+                L, Min = 2.5, float(gm.model.Y.min())
+                lp.update_batches(Xb, L, Min)
+                r0, s0 = O.lp_hammer_precompute(gm, Xb, L, Min)
+                assert np.array_equal(lp.r_x0, r0) and np.array_equal(lp.s_x0, s0)
+                neg = base.acquisition_function(Xs)
+                ref = lp.acquisition_function(Xs)
+                mine = O.lp_penalized_acquisition(neg, Xs, Xb, r0, s0, transform)
+                worst = max(worst, float(np.max(np.abs(ref - mine) / np.maximum(1.0, np.abs(ref)))))
+                # gradient: the reference only broadcasts for one row at a time (LP.py:112-133)
+                for r in range(4, Xs.shape[0], 7):   # rows 0..2 are the batch points themselves (|x - x0| = 0)
+                    xr = Xs[r:r + 1]
+                    negr, negdr = base.acquisition_function_withGradients(xr)   # as the reference evaluates it: one row
+                    gref = lp.d_acquisition_function(xr)
+                    gmine = O.lp_d_acquisition(negr, negdr, xr, Xb, r0, s0, transform)
+                    worst = max(worst, float(np.max(np.abs(gref - gmine) / np.maximum(1.0, np.abs(gref)))))
+    assert worst < 1e-13, worst
+    return "AcquisitionEI/LCB/MPI verbatim == oracle bit-identical; AcquisitionLP value/gradient within %.1e" % worst
+
+
+def check_lp_evaluator(A):
+    """estimate_L and LocalPenalization.compute_batch of the verbatim evaluator module against the oracle's, same
+    numpy seed, oracle-backed model; compute_batch with the acquisition's optimiser replaced by an arg-min over a fixed
+    candidate table (the optimiser itself is scipy, out of scope)."""
+    ev = A["lp_evaluator"]
+    gm, Xs = _oracle_model("Mat52", seed=5)
+    bounds = [(0.0, 1.0)] * Xs.shape[1]
+    np.random.seed(7)
+    try:
+        L_ref = ev.estimate_L(gm.model, bounds)
+    except (TypeError, IndexError, ValueError) as e:
+        # scipy >= 1.5 hands minimize()'s scalar `fun` back as a float; the reference (pinned to scipy 1.2.0,
+        # to_install.txt:12) indexes it as res.fun[0][0].  Its algorithm up to that line is what can run here.
+        L_ref = None
+        note = "reference estimate_L does not run on this scipy (%s: %s)" % (type(e).__name__, e)
+    np.random.seed(7)
+    L_mine = O.estimate_L(gm.model, bounds)
+    if L_ref is not None:
+        assert abs(L_ref - L_mine) <= 1e-12 * abs(L_ref), (L_ref, L_mine)
+        note = "estimate_L verbatim == oracle (%.12g)" % L_mine
+    else:
+        # same sampling stream and the same starting point: replay the reference's lines 60-65 by hand
+        np.random.seed(7)
+        gen = sys.modules["GPyOpt.util.general"]
+        samples = np.vstack([gen.samples_multidimensional_uniform(bounds, 500), gm.model.X])
+        dm, _ = gm.model.predictive_gradients(samples)
+        start = -np.sqrt((dm * dm).sum(1)).min()
+        assert L_mine >= -start - 1e-12, (L_mine, start)
+    space = _Space(bounds)
+    table = Xs
+
+    class TableLP(A["LP"].AcquisitionLP):
+        def optimize(self, duplicate_manager=None):
+            a = self.acquisition_function(table)
+            i = int(np.argmin(a))
+            return table[i:i + 1], a[i]
+    gm.analytical_gradient_prediction = True
+    base = A["EI"].AcquisitionEI(gm, space, None, None, jitter=0.01)
+    sys.modules["GPyOpt.acquisitions"].AcquisitionLP = A["LP"].AcquisitionLP
+    lp = TableLP(gm, space, None, base)
+    saved = ev.estimate_L
+    if L_ref is None:
+        ev.estimate_L = O.estimate_L   # the verbatim batch loop around the one function that cannot run here
+    try:
+        np.random.seed(11)
+        B_ref = ev.LocalPenalization(lp, 4).compute_batch()
+    finally:
+        ev.estimate_L = saved
+    np.random.seed(11)
+    B_mine = O.lp_compute_batch(TableLP(gm, space, None, base), 4)
+    assert B_ref.shape == (4, Xs.shape[1]) and np.array_equal(B_ref, B_mine)
+    note += "; LocalPenalization.compute_batch verbatim == oracle (4 points)"
+    return note
+
+
 def main():
     if not ref_leaf.available():
         print("reference tree absent: cannot pin"); return 2
@@ -207,6 +331,9 @@ def main():
     print(check_native(lib))
     print(check_lml_through_reference(R))
     print(check_invariants())
+    A = ref_leaf.load_acquisitions()
+    print(check_acquisitions(A))
+    print(check_lp_evaluator(A))
     print("ORACLE PINNED")
     return 0
 

@@ -43,6 +43,33 @@ def load():
     return linalg, diag, normalizer, general
 
 
+def load_acquisitions():
+    """The reference's acquisition layer, verbatim: GPyOpt.acquisitions.{base,EI,LCB,MPI,LP} and
+    GPyOpt.core.evaluators.batch_local_penalization (estimate_L, LocalPenalization).
+
+    Their import chain reaches ``GPyOpt.models`` (-> GPy -> paramz, absent) only for the NAME ``GPModel`` that
+    core/task/cost.py binds at import time and never touches on this path (constant cost); an empty placeholder
+    module supplies that name, every other module on the chain is the reference's own file.  Returns a dict of modules.
+    """
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF)
+    load()
+    _pkg("GPyOpt.core.task", REF + "/GPyOpt/GPyOpt/core/task")
+    _pkg("GPyOpt.core.evaluators", REF + "/GPyOpt/GPyOpt/core/evaluators")
+    _pkg("GPyOpt.acquisitions", REF + "/GPyOpt/GPyOpt/acquisitions")
+    if "GPyOpt.models" not in sys.modules:
+        m = types.ModuleType("GPyOpt.models")
+        m.GPModel = type("GPModel", (object,), {})   # name only; see the docstring
+        sys.modules["GPyOpt.models"] = m
+    names = {"base": "GPyOpt.acquisitions.base", "EI": "GPyOpt.acquisitions.EI", "LCB": "GPyOpt.acquisitions.LCB",
+             "MPI": "GPyOpt.acquisitions.MPI", "LP": "GPyOpt.acquisitions.LP",
+             "lp_evaluator": "GPyOpt.core.evaluators.batch_local_penalization"}
+    mods = {k: importlib.import_module(v) for k, v in names.items()}
+    # compute_batch does ``from ...acquisitions import AcquisitionLP`` at call time
+    sys.modules["GPyOpt.acquisitions"].AcquisitionLP = mods["LP"].AcquisitionLP
+    return mods
+
+
 def load_stationary_utils():
     """ctypes handle on oracle/_ref/libstationary_utils.so (reference C, compiled by oracle/Makefile)."""
     path = os.path.join(HERE, "_ref", "libstationary_utils.so")

@@ -25,6 +25,14 @@ def test_lml_through_reference():
     pin.check_lml_through_reference(ref_leaf.load())
 
 
+@needs_ref
+def test_acquisition_layer_verbatim():
+    """EI / LCB / MPI / LP and the local-penalisation evaluator: the reference's own modules on an oracle-backed model."""
+    A = ref_leaf.load_acquisitions()
+    assert "bit-identical" in pin.check_acquisitions(A)
+    assert "compute_batch verbatim == oracle" in pin.check_lp_evaluator(A)
+
+
 def test_reference_test_invariants():
     # pinv closed form, var >= 0, normaliser equivalence, finite-difference gradients (no reference import needed)
     pin.check_invariants()

@@ -30,7 +30,23 @@ def _worker(rank, world, port, q):
         sc = ShardedCandidates(rank, world, TorchCollective(world))
         out = [sc.argbest(Xs, score_local, s) for s in (-1, +1)]
         full = -O.acq_EI(gm, Xs, 0.01, fmin)[:, 0]
-        q.put((rank, out, (int(np.argmin(full)), float(full.min())), (int(np.argmax(full)), float(full.max()))))
+        # top-k (anchor_points_generator.py:61 keeps 5 anchors): the best row is duplicated into the OTHER shard, so
+        # the cross-shard tie is among the winners and must come out lowest global index first
+        Xt = Xs.copy()
+        b = int(np.argmin(full))
+        twin = b + 151 if b < 150 else b - 150   # shards are rows [0, 151) and [151, 301)
+        Xt[twin] = Xt[b]
+        fullt = -O.acq_EI(gm, Xt, 0.01, fmin)[:, 0]
+
+        def score_local_topk(Xb, k, sense):  # stands in for Acquisition.topk on the HIP path
+            a = -O.acq_EI(gm, Xb, 0.01, fmin)[:, 0]
+            o = np.argsort(a if sense < 0 else -a, kind="stable")[:k]
+            return o, a[o]
+        topk = [sc.topk(Xt, score_local_topk, 5, s) for s in (-1, +1)]
+        ref_topk = [np.argsort(fullt, kind="stable")[:5], np.argsort(-fullt, kind="stable")[:5]]
+        q.put((rank, out, (int(np.argmin(full)), float(full.min())), (int(np.argmax(full)), float(full.max())),
+               [(t[0].tolist(), t[1].tolist()) for t in topk], [r.tolist() for r in ref_topk],
+               [fullt[r].tolist() for r in ref_topk], (min(b, twin), max(b, twin))))
     finally:
         dist.destroy_process_group()
 
@@ -47,7 +63,12 @@ def test_sharded_argbest_world2_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, out, ref_min, ref_max in res:
+    for rank, out, ref_min, ref_max, topk, ref_idx, ref_val, tie in res:
         assert out[0][0] == ref_min[0] and out[0][1] == pytest.approx(ref_min[1], rel=1e-12)
         assert out[1][0] == ref_max[0] and out[1][1] == pytest.approx(ref_max[1], rel=1e-12)
-    assert res[0][1] == res[1][1]  # both ranks agree
+        for s in range(2):
+            assert topk[s][0] == ref_idx[s]
+            assert topk[s][1] == pytest.approx(ref_val[s], rel=1e-12)
+        # the duplicated best row and its twin in the other shard lead the list, lower global index first
+        assert topk[0][0][:2] == list(tie) and topk[0][1][0] == topk[0][1][1]
+    assert res[0][1] == res[1][1] and res[0][4] == res[1][4]  # both ranks agree

@@ -1,22 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline metric of BASELINE.json on MI355X: GP fit+predict iterations/s at N=16384, D=8.
 
-A "step" is one pass of the hot path over one batch of synthetic input:
-    fit      (K build -> Cholesky -> alpha -> LML)                     SURVEY.md 8a rows A1-A5
-    predict  on the rank's 10 000 resident candidates                   rows A6-A7
-             (both through ONE call, gp_fit_predict; --separate-calls times gp_fit + gp_predict instead)
-    EI scoring of those candidates + device arg-best                    rows A9-A11, A14
-    (N > 1) one RCCL all-gather of the per-shard (best, index) pair     SURVEY.md 8e
-Inputs are resident in HBM before the timed region; hyper-parameters are fixed.
+A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM before the timed region,
+hyper-parameters fixed.
 
-Multi-GPU (one process per GPU, launched by torch.distributed.run): the candidate table shards
-across ranks, the fit is REPLICATED on every rank ("replicas only" for the fit), so
-per-GPU work is fixed as N grows ("weak").  `value` counts the fit+predict units all ranks
-processed per second; config.job_iters_per_s is the rate of whole sharded iterations.
-torch is imported only for N > 1 (rendezvous + barrier over gloo); the data path is libgphip
-(ctypes) and its RCCL communicator.
+--gpus 1 (default)  workload C3 = BASELINE.json configs[2], the configuration the metric is quoted on:
+    fit (K build -> Cholesky -> alpha -> LML, rows A1-A5) + predict on 10 000 resident candidates (A6-A7), both
+    through ONE call (gp_fit_predict; --separate-calls times gp_fit + gp_predict instead), + EI scoring + device
+    arg-best (A9-A11, A14).  value = iterations/s.
+
+--gpus N > 1        workload C4 = BASELINE.json configs[3]: N=16384, D=8 Matern-5/2, ONE candidate table of 10^6 rows
+    split over the ranks (contiguous row blocks), per iteration: fit (replicated on every rank: the fit does not shard,
+    SURVEY.md 8e) + posterior + EI over the rank's block + device arg-best + ONE RCCL all-gather of the per-rank
+    (best value, global row) pair over xGMI + the lowest-index merge.  Total work is fixed as N grows ("strong" -- of
+    the predict/EI part; the fit's share is reported separately and does not scale).  value = whole sharded
+    iterations/s (NOT multiplied by the rank count).  One process per GPU, launched by torch.distributed.run;
+    torch is used for rendezvous / barrier / max-over-ranks only (gloo), the data path is libgphip + its RCCL
+    communicator.  --workload c3|c4 overrides the automatic choice (e.g. C4 on one GPU as the strong-scaling base).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,7 +30,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X vendor dense FP64 matrix peak (v_mfma_f64_16x16x4_f64); see DESIGN.md
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz); see DESIGN.md
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 achievable)
+GEMM_SYMBOL = "gemm_nt_kernel<1, 128, 4, false, 128>"
 
 
 def synthetic(N, D, M, seed=1234, cand_seed=None):
@@ -42,9 +47,20 @@ def synthetic(N, D, M, seed=1234, cand_seed=None):
     return X, Y, Xs
 
 
-def cpu_baseline(N, D, M):
-    """The oracle (NumPy/SciPy restatement of the reference's path) timed on this host, on a bounded
-    sample: N/2, M/2 of the same workload = 1/8 of its flops; the time is scaled by that ratio."""
+def shard_bounds(M, rank, nranks):
+    base, rem = divmod(int(M), int(nranks))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def cpu_baseline(N, D, M, full=False):
+    """The oracle (NumPy/SciPy restatement of the reference's path, same LAPACK entry points as GPy) timed on this
+    host's cores, phase by phase.  Default: a bounded sample (N/2, M/2) with EACH PHASE scaled by its own exponent to
+    the quoted size (K builds ~ N^2 resp. N M, dpotrf / dtrtri / dpotri ~ N^3, dtrtrs ~ N^2 M, symmetrify ~ N^2);
+    --cpu-baseline-full runs the quoted size itself (several minutes).  Two totals: "minimal" = what is
+    algebraically needed (K, dpotrf, dpotrs, K*, dtrtrs); "as GPy does it" adds what pdinv computes regardless
+    (dtrtri, linalg.py:209; dpotri + two symmetrify, :144,210-212) and one get_fmin recomputation
+    (predict at the N training inputs, GPyOpt models/gpmodel.py:125-129: K(X,X) again + an N x N dtrtrs)."""
     from oracle import cpu_ref as O
     try:
         from threadpoolctl import threadpool_info
@@ -52,19 +68,64 @@ def cpu_baseline(N, D, M):
         cores = max([n for _, n in blas if n] or [os.cpu_count()])
     except Exception:  # noqa: BLE001
         blas, cores = [], os.cpu_count()
-    Ns, Ms = N // 2, M // 2
+    Ns, Ms = (N, M) if full else (N // 2, M // 2)
+    rn, rm = N / Ns, M / Ms
     X, Y, Xs = O.synthetic_problem(Ns, D, Ms, seed=1234)
     kern = O.RBF(D, 1.0, O.default_lengthscale(D, False))
-    t0 = time.perf_counter()
-    lml, mu, var, phases = O.fit_predict_iteration(kern, X, Y, 1e-2, Xs, as_gpy=False)
-    t = time.perf_counter() - t0
-    flops_full = N ** 3 / 3.0 + float(N) * N * M
-    flops_s = Ns ** 3 / 3.0 + float(Ns) * Ns * Ms
-    scale = flops_full / flops_s
-    return {"value": 1.0 / (t * scale), "unit": "fit+predict iters/s", "cores": int(cores), "kind": "port",
-            "sample": "N=%d, M=%d (1/%.0f of the flops of N=%d, M=%d), minimal path (K, dpotrf, dpotrs, K*, dtrtrs); "
-                      "measured %.2f s, scaled by %.1f" % (Ns, Ms, scale, N, M, t, scale),
-            "phases_s": {k: round(v, 3) for k, v in phases.items()}, "blas": blas}
+    ph, scale = {}, {}
+
+    def timed(name, factor, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        ph[name] = time.perf_counter() - t0
+        scale[name] = factor
+        return out
+    Ky = timed("K_build", rn ** 2, lambda: kern.K(X))
+    O.diag_add(Ky, 1e-2 + 1e-8)
+    L = timed("dpotrf", rn ** 3, lambda: O.jitchol(Ky)[0])
+    del Ky
+    alpha = timed("dpotrs_alpha_lml", rn ** 2, lambda: O.dpotrs(L, Y, lower=1)[0])
+    Kx = timed("K_cross", rn * rm, lambda: kern.K(X, Xs))
+    tmp = timed("dtrtrs_var", rn ** 2 * rm, lambda: (np.dot(Kx.T, alpha), 1.0 - np.square(O.dtrtrs(L, Kx)[0]).sum(0)))
+    del Kx, tmp
+    minimal = sum(ph[k] * scale[k] for k in ph)
+    # what GPy does on top (pdinv, get_fmin)
+    timed("dtrtri_unused_by_inference", rn ** 3, lambda: O.dtrtri(L))
+    Wi = timed("dpotri", rn ** 3, lambda: O.dpotri(L, lower=1)[0])
+    timed("symmetrify_x2", rn ** 2, lambda: (O.symmetrify(Wi), O.symmetrify(Wi)))
+    del Wi
+    Kxx = timed("get_fmin_K", rn ** 2, lambda: kern.K(X, X))
+    timed("get_fmin_dtrtrs", rn ** 3, lambda: O.dtrtrs(L, Kxx)[0])
+    as_gpy = sum(ph[k] * scale[k] for k in ph)
+    return {"value": 1.0 / minimal, "unit": "fit+predict iters/s", "cores": int(cores), "kind": "port",
+            "sample": ("the quoted size itself: N=%d, M=%d" % (N, M)) if full else
+                      ("N=%d, M=%d (half of N=%d, M=%d in both), each phase scaled by its own exponent "
+                       "(phases_scale); measured %.1f s of CPU work" % (Ns, Ms, N, M, sum(ph.values()))),
+            "total_minimal_s": minimal, "total_as_gpy_does_it_s": as_gpy, "value_as_gpy_does_it": 1.0 / as_gpy,
+            "phases_measured_s": {k: round(v, 3) for k, v in ph.items()},
+            "phases_scale": {k: round(v, 3) for k, v in scale.items()},
+            "phases_at_quoted_size_s": {k: round(ph[k] * scale[k], 3) for k in ph}, "blas": blas,
+            "full_size_run": "profiles/r02_cpu_baseline_full.json (one run of --cpu-baseline-full on the GPU box's host)"}
+
+
+def static_traffic(N, D, M):
+    """HBM-side traffic of the dominant kernel from the committed PMC passes of THIS command (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, tools/pmc_traffic.py).  Not measured by this run: carried with its
+    provenance and dropped when gemm.hip has changed since the passes were taken."""
+    tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+    if not os.path.exists(tpath) or (N, D, M) != (16384, 8, 10000):
+        return None, None
+    with open(tpath) as f:
+        tj = json.load(f)
+    src = os.path.join(ROOT, "gaussian_process_optimization_amd", "csrc", "gemm.hip")
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    if tj.get("gemm_hip_sha256_16") != sha:
+        return None, {"static": True, "dropped": "gemm.hip changed since the counter passes (%s != %s)"
+                                                 % (tj.get("gemm_hip_sha256_16"), sha)}
+    return tj["traffic_bytes_per_launch"], {"static": True, "file": "profiles/r02_gemm_traffic.json",
+                                            "kernel": GEMM_SYMBOL, "launches": tj["launches"],
+                                            "gemm_hip_sha256_16": sha,
+                                            "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch")}
 
 
 def main():
@@ -72,23 +133,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="auto", choices=["auto", "c3", "c4"])
     ap.add_argument("--N", type=int, default=16384)
     ap.add_argument("--D", type=int, default=8)
-    ap.add_argument("--M", type=int, default=10000, help="candidates per GPU")
-    ap.add_argument("--kernel", default="rbf", choices=["rbf", "Mat52"])
+    ap.add_argument("--M", type=int, default=0, help="candidates: C3 default 10 000 (per GPU), C4 default 10^6 (whole table)")
     ap.add_argument("--panel-tiles", type=int, default=0)
+    ap.add_argument("--option", action="append", default=[], help="name=value passed to gp_set_option (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="time the oracle at the quoted size (minutes)")
     ap.add_argument("--separate-calls", action="store_true",
-                    help="time gp_fit + gp_predict as two calls instead of the one-call entry point gp_fit_predict")
-    ap.add_argument("--extras", action="store_true", help="also time the other of the two call patterns (un-timed region)")
+                    help="C3: time gp_fit + gp_predict as two calls instead of the one-call entry point gp_fit_predict")
+    ap.add_argument("--no-c4-reference", action="store_true",
+                    help="C4, N > 1: skip rank 0's un-timed single-GPU pass over the whole table (the strong-scaling base)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
     dist = None
     if world > 1:
         import torch.distributed as dist  # plumbing only: rendezvous, barrier, max-over-ranks
@@ -96,24 +160,40 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from gaussian_process_optimization_amd import _lib
+    from gaussian_process_optimization_amd.sharded import merge_best
     # rehearsal switch for a one-GPU box: every rank on device 0 (RCCL then refuses the duplicate device and the
     # exchange falls back to gloo); never set by the driver
     dev = 0 if os.environ.get("GPHIP_BENCH_SAME_DEVICE") else local_rank
     h = _lib.Handle(dev)
     if args.panel_tiles:
         h.set_option("panel_tiles", args.panel_tiles)
-    N, D, M = args.N, args.D, args.M
-    X, Y, Xs = synthetic(N, D, M, cand_seed=1236 + rank)   # every rank: same model data, its own candidate shard
-    kid = _lib.GP_KERNEL_RBF if args.kernel == "rbf" else _lib.GP_KERNEL_MATERN52
+    for kv in args.option:
+        k, v = kv.split("=")
+        h.set_option(k, int(v))
+    N, D = args.N, args.D
+    if workload == "c3":
+        M_total = (args.M or 10000) * world          # every rank its own 10 000 candidates
+        M = args.M or 10000
+        lo = rank * M
+        X, Y, Xs = synthetic(N, D, M, cand_seed=1236 + rank)
+        kid, kname = _lib.GP_KERNEL_RBF, "RBF"
+    else:
+        M_total = args.M or 1000000
+        lo, hi = shard_bounds(M_total, rank, world)
+        M = hi - lo
+        X, Y, _ = synthetic(N, D, 8)
+        # ONE table for the whole job (seed 1236), this rank's contiguous block of it
+        Xs = np.random.default_rng(1236).uniform(0, 1, (M_total, D))[lo:hi].copy()
+        kid, kname = _lib.GP_KERNEL_MATERN52, "Matern52"
     h.set_data(X, Y)
     h.set_params(kid, 0, 1.0, [0.25 * np.sqrt(D)], 1e-2)
     h.set_candidates(Xs)
-    collective = None
+    collective, rccl_ranks = None, None
     if world > 1:
         import torch
         # the one data-path collective: an all-gather of 16 bytes per rank over RCCL.  If the RCCL
         # communicator cannot be built on this node every rank agrees to fall back to the rendezvous backend (gloo)
-        # for that exchange -- said in the JSON line -- so that the scaling run still measures the sharded path.
+        # for that exchange -- said in the JSON line: such a line is not an RCCL measurement.
         ok = 1
         try:
             uid = [h.comm_unique_id() if rank == 0 else None]
@@ -126,12 +206,13 @@ def main():
         if ok:
             try:
                 h.comm_init(uid[0], rank, world)
+                rccl_ranks = h.comm_info()[1]
             except Exception as e:  # noqa: BLE001
                 ok = 0
                 sys.stderr.write("rank %d: RCCL comm init failed: %s\n" % (rank, e))
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        collective = "rccl" if int(flag.item()) == 1 else "gloo (RCCL communicator unavailable)"
+        collective = "rccl" if int(flag.item()) == 1 else "gloo (RCCL communicator unavailable: NOT an RCCL measurement)"
 
     def barrier():
         h.synchronize()
@@ -139,41 +220,61 @@ def main():
             dist.barrier()
         h.synchronize()
 
-    def step(pipelined=False):
-        if pipelined:  # gp_fit + gp_predict as one pipelined pass (same results; see include/gphip.h)
+    def exchange(val, gidx):
+        if world == 1:
+            return gidx, val
+        if collective == "rccl":
+            vals, idxs = h.comm_allgather_best(val, gidx, world)
+        else:
+            import torch
+            mine = torch.tensor([val, float(gidx)], dtype=torch.float64)
+            allp = [torch.empty(2, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(allp, mine)
+            vals = np.array([float(t[0]) for t in allp])
+            idxs = np.array([int(t[1]) for t in allp], dtype=np.int64)
+        return merge_best(vals, idxs, -1)
+
+    fused = workload == "c3" and not args.separate_calls
+
+    def step():
+        if fused:  # gp_fit + gp_predict as one pipelined pass (bitwise the same results; include/gphip.h)
             (lml, logdet, jit), mu, var = h.fit_predict(True)
         else:
             lml, logdet, jit = h.fit()
-            mu, var = h.predict(True)
+            if workload == "c3":
+                mu, var = h.predict(True)
         fmin = h.fmin()
-        idx, val = h.acq_argbest(_lib.GP_ACQ_EI, 0.01, fmin, -1)
-        if world > 1:
-            from gaussian_process_optimization_amd.sharded import merge_best
-            if collective == "rccl":
-                vals, idxs = h.comm_allgather_best(val, rank * M + idx, world)
-            else:
-                import torch
-                mine = torch.tensor([val, float(rank * M + idx)], dtype=torch.float64)
-                allp = [torch.empty(2, dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(allp, mine)
-                vals = np.array([float(t[0]) for t in allp])
-                idxs = np.array([int(t[1]) for t in allp], dtype=np.int64)
-            idx, val = merge_best(vals, idxs, -1)
-        return lml, idx, val
+        idx, val = h.acq_argbest(_lib.GP_ACQ_EI, 0.01, fmin, -1)   # C4: posterior + EI over the block, chunked
+        gi, gv = exchange(val, lo + idx)
+        return lml, gi, gv
 
-    # the timed step goes through gp_fit_predict (fit + predict as one call: bitwise the results of the two calls,
-    # tests/test_gpu_parity.py; the first candidate stages ride behind the factorisation's latency-bound tail)
-    fused = not args.separate_calls
+    # C4 on N > 1 ranks: rank 0 times one un-profiled pass over the WHOLE table on its own GPU first (the single-GPU
+    # base the sharded rate is to be read against); the other ranks wait at the barrier
+    c4_ref = None
+    if workload == "c4" and world > 1 and not args.no_c4_reference:
+        if rank == 0:
+            full = np.random.default_rng(1236).uniform(0, 1, (M_total, D))
+            h.set_candidates(full)
+            h.fit(); h.acq_argbest(_lib.GP_ACQ_EI, 0.01, h.fmin(), -1)     # warm-up (allocations)
+            h.synchronize()
+            t0 = time.perf_counter()
+            h.fit()
+            i1, v1 = h.acq_argbest(_lib.GP_ACQ_EI, 0.01, h.fmin(), -1)
+            h.synchronize()
+            c4_ref = {"single_gpu_iter_s": time.perf_counter() - t0, "best_row": int(i1), "best_value": v1}
+            del full
+            h.set_candidates(Xs)
+        barrier()
+
     for _ in range(args.warmup):
-        out = step(fused)
-    h.profile(True)          # HIP events around every launch of the dominant kernel (fp64 MFMA GEMM)
+        out = step()
+    h.profile(True)          # HIP events around every launch of the dominant kernel (fp64 MFMA GEMM), on its stream
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step(fused)
+        out = step()
     barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed = time.perf_counter() - t0
     gs = h.gemm_stats()
     busy_ms = h.gemm_busy()
     phases_timed = {p["name"]: round(p["ms"], 3) for p in h.phases()}   # of the last call of the last timed step
@@ -184,85 +285,88 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # un-timed extras: the same step through the pipelined entry point (gp_fit_predict), and phase breakdowns
-    pipelined_ms, phases_pipelined = None, None
-    other_roofline = None
-    if args.extras:
-        step(not fused)
-        h.profile(True)
-        h.synchronize()
-        tp0 = time.perf_counter()
-        for _ in range(3):
-            step(not fused)
-        h.synchronize()
-        pipelined_ms = (time.perf_counter() - tp0) / 3 * 1e3
-        phases_pipelined = {p["name"]: round(p["ms"], 3) for p in h.phases()}
-        gs2 = h.gemm_stats()
-        h.profile(False)
-        a2 = gs2["flops"] / max(gs2["ms"], 1e-9) / 1e9
-        other_roofline = {"achieved": a2, "frac": a2 / FP64_MFMA_PEAK_TFLOPS, "launches": gs2["launches"],
-                          "avg_launch_ms": gs2["ms"] / max(gs2["launches"], 1)}
+    # un-timed: per-phase rates from one gp_fit and one gp_predict run one after the other
     h.fit()
     ph_fit = h.phases()
-    h.predict(True)
+    fit_ms = sum(p["ms"] for p in ph_fit)
+    if workload == "c3":
+        h.predict(True)
+    else:
+        h.acq_argbest(_lib.GP_ACQ_EI, 0.01, h.fmin(), -1)
     ph_pred = h.phases()
-    phases = {p["name"]: round(p["ms"], 3) for p in ph_fit + ph_pred}
+    phases = {p["name"]: round(p["ms"], 3) for p in ph_fit}
+    for p in ph_pred:   # (a chunked predict reports its LAST chunk's phases: gp_last_phases holds one call's worth)
+        phases[p["name"]] = round(p["ms"], 3)
     chol = [p for p in ph_fit if p["name"] == "cholesky"][0]
-    solve = [p for p in ph_pred if p["name"] == "cand_solve"][0]
-
-    # HBM-side traffic of the dominant kernel: PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in separate
-    # rocprofv3 --pmc runs, gfx950 correction applied; tools/pmc_traffic.py), averaged per big launch like `achieved`
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-    if os.path.exists(tpath) and (N, D, M) == (16384, 8, 10000):
-        with open(tpath) as f:
-            tj = json.load(f)
-        traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_gemm_traffic.json (rocprofv3 --pmc, %d launches)" % tj["launches"]
+    kb = [p for p in ph_fit if p["name"] == "kbuild"][0]
+    solve = [p for p in ph_pred if p["name"] == "cand_solve"][-1]
 
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         job_rate = args.steps / elapsed
         achieved = gs["flops"] / max(gs["ms"], 1e-9) / 1e9
+        traffic, traffic_src = static_traffic(N, D, M) if workload == "c3" else (None, None)
+        kb_gbs = kb["bytes"] / max(kb["ms"], 1e-9) / 1e6
+        if workload == "c3":
+            cfg = {"workload": "C3 (BASELINE.json configs[2]): N=%d, D=%d RBF iso, fit (K, Cholesky, alpha, LML) + predict "
+                               "mean/var at M=%d candidates per GPU + EI arg-best" % (N, D, M),
+                   "candidates_per_gpu": M, "entry_point": "gp_fit_predict" if fused else "gp_fit + gp_predict"}
+            scaling, value = "weak", world * job_rate
+            if world > 1:
+                cfg["note_n_gpus"] = ("C3 on N > 1 ranks replicates the fit and gives every rank its own 10^4 candidates: "
+                                      "value counts N replicas and says nothing about scaling; the scaling workload is C4")
+        else:
+            cfg = {"workload": "C4 (BASELINE.json configs[3]): N=%d, D=%d Matern-5/2 iso, fit (replicated per rank) + posterior "
+                               "+ EI over ONE table of %d candidates split over %d rank(s) + device arg-best + RCCL "
+                               "all-gather of (best, row) + lowest-index merge" % (N, D, M_total, world),
+                   "candidates_total": M_total, "candidates_this_rank": M,
+                   "fit_ms_per_iter_not_scaling": round(fit_ms, 3),
+                   "predict_ei_ms_per_iter_this_rank": round(ms_per_step - fit_ms, 3),
+                   "single_gpu_reference": c4_ref,
+                   "speedup_vs_single_gpu": None if not c4_ref else c4_ref["single_gpu_iter_s"] * 1e3 / ms_per_step,
+                   "best_row_matches_single_gpu": None if not c4_ref else bool(c4_ref["best_row"] == int(out[1]))}
+            scaling, value = "strong", job_rate
+        cfg.update({"kernel": kname, "noise": 1e-2, "fit": "replicated on every rank (does not shard, SURVEY.md 8e)",
+                    "collective": collective, "rccl_comm_ranks": rccl_ranks, "job_iters_per_s": job_rate,
+                    "lml": out[0], "best_candidate_global_row": int(out[1]), "best_value": float(out[2]),
+                    "phases_ms_last_timed_call": phases_timed, "phases_ms": phases,
+                    "phases_note": "phases_ms: one gp_fit and one predict pass run one after the other AFTER the timed "
+                                   "region (the per-phase rates below come from it)",
+                    "cholesky_tflops": chol["flops"] / chol["ms"] / 1e9,
+                    "cholesky_frac_of_fp64_mfma_peak": chol["flops"] / chol["ms"] / 1e9 / FP64_MFMA_PEAK_TFLOPS,
+                    "cand_solve_tflops": solve["flops"] / solve["ms"] / 1e9})
         result = {
             "metric": "GP fit+predict iters/sec at N=%d D=%d" % (N, D),
-            "value": world * job_rate,
-            "unit": "fit+predict iters/s",
+            "value": value, "unit": "fit+predict iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3: N=%d, D=%d %s iso, fit (K, Cholesky, alpha, LML) + predict mean/var at "
-                                   "M=%d candidates per GPU + EI arg-best" % (N, D, args.kernel, M),
-                       "noise": 1e-2, "candidates_per_gpu": M, "fit": "replicated on every rank", "collective": collective,
-                       "job_iters_per_s": job_rate, "lml": out[0], "best_candidate": int(out[1]),
-                       "phases_ms_last_timed_call": phases_timed,
-                       "phases_ms": phases, "phases_note": "phases_ms: gp_fit and gp_predict run one after the other "
-                                                           "after the timed region (per-phase rates below come from it)",
-                       "entry_point": "gp_fit_predict" if fused else "gp_fit + gp_predict",
-                       "other_call_pattern": None if pipelined_ms is None else {
-                           "entry_point": "gp_fit + gp_predict" if fused else "gp_fit_predict",
-                           "ms_per_step": pipelined_ms, "iters_per_s": 1e3 / pipelined_ms, "phases_ms": phases_pipelined,
-                           "roofline_same_kernel": other_roofline},
-                       "cholesky_tflops": chol["flops"] / chol["ms"] / 1e9,
-                       "cholesky_frac_of_fp64_mfma_peak": chol["flops"] / chol["ms"] / 1e9 / FP64_MFMA_PEAK_TFLOPS,
-                       "cand_solve_tflops": solve["flops"] / solve["ms"] / 1e9},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<1, 128, 4, false, 128> (C -= A B^T on fp64 v_mfma_f64_16x16x4_f64, 8 waves)",
+            "config": cfg,
+            "roofline": {"bound": "mfma", "kernel": GEMM_SYMBOL + " (C -= A B^T on fp64 v_mfma_f64_16x16x4_f64, 8 waves)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_src,
-                         "note": ("in gp_fit_predict three candidate-update launches and the trailing updates of the "
-                                  "factorisation's tail run CONCURRENTLY (that is where the entry point gains its 5 %): their "
-                                  "durations, hence this average, include the time they share the chip; achieved_while_running = the "
-                                  "same flops / the union of the launches' intervals; --separate-calls times the same kernel "
-                                  "without overlap (0.74 of peak, profiles/)") if fused else None,
+                         "traffic_provenance": traffic_src,
+                         "note": ("HIP events bracket every launch of this kernel symbol INSIDE the timed region (~29 per step), "
+                                  "on the stream each is launched on.  In gp_fit_predict a few candidate-update launches and "
+                                  "the trailing updates of the factorisation's tail run concurrently: a launch's duration "
+                                  "includes the time it shares the chip; achieved_while_running = the same flops / the union "
+                                  "of the launches' intervals") if fused else
+                                 "HIP events bracket every launch of this kernel symbol inside the timed region, on its stream",
                          "launches": gs["launches"], "kernel_ms_total": gs["ms"],
-                         "launch_filter": "every launch of that kernel symbol in the timed region (launches of >= 1400 output tiles: trailing updates, candidate updates; > 90 % of the flops)", "avg_launch_ms": gs["ms"] / max(gs["launches"], 1),
+                         "launch_filter": "every launch of that kernel symbol in the timed region (launches of >= 1400 output "
+                                          "tiles: trailing updates, candidate updates; > 90 % of the flops)",
+                         "avg_launch_ms": gs["ms"] / max(gs["launches"], 1),
                          "busy_ms_total": busy_ms, "achieved_while_running": gs["flops"] / max(busy_ms, 1e-9) / 1e9,
                          "frac_while_running": gs["flops"] / max(busy_ms, 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS,
                          "flops_per_launch_avg": gs["flops"] / max(gs["launches"], 1)},
+            "kbuild": {"bound": "hbm", "kernel": "kbuild_kernel (+ set_rhs_kernel: the 'kbuild' phase of gp_fit, HIP events)",
+                       "algorithmic_bytes": kb["bytes"], "ms": kb["ms"], "achieved": kb_gbs, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": kb_gbs / HBM_PEAK_GBS,
+                       "counter_evidence": "profiles/r02_kbuild_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(N, D, M)
+            result["cpu_baseline"] = cpu_baseline(N, D, 10000, full=args.cpu_baseline_full)
         print(json.dumps(result))
         sys.stdout.flush()
     if dist is not None:

@@ -69,6 +69,7 @@ SIGNATURES = [
     ("gp_comm_unique_id", ctypes.c_int, [ctypes.c_char_p]),
     ("gp_comm_init", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     ("gp_comm_destroy", ctypes.c_int, [_vp]),
+    ("gp_comm_info", ctypes.c_int, [_vp, c_int_p, c_int_p]),
     ("gp_comm_allgather_best", ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int64, c_double_p, c_int64_p]),
     ("gp_comm_bcast_fit", ctypes.c_int, [_vp, ctypes.c_int]),
     ("gp_last_phases", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), c_double_p, c_double_p,
@@ -392,6 +393,11 @@ class Handle(object):
 
     def comm_init(self, uid, rank, nranks):
         check(self.lib, self.lib.gp_comm_init(self.h, uid, int(rank), int(nranks)), "gp_comm_init")
+
+    def comm_info(self):
+        r, n = ctypes.c_int(), ctypes.c_int()
+        check(self.lib, self.lib.gp_comm_info(self.h, ctypes.byref(r), ctypes.byref(n)), "gp_comm_info")
+        return r.value, n.value
 
     def comm_allgather_best(self, val, idx, nranks):
         vals = np.empty(nranks)

@@ -1536,6 +1536,19 @@ int gp_comm_init(gp_t *g, const char *uid128, int rank, int nranks) {
     return 0;
 }
 
+// what the communicator itself reports (ncclCommCount / ncclCommUserRank): the bench line carries these
+int gp_comm_info(gp_t *g, int *rank, int *nranks) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
+    if (!g->comm) return fail(GP_ERR_STATE, "gp_comm_init first");
+    int r = -1, n = -1;
+    NCCLCHK(ncclCommUserRank(g->comm, &r));
+    NCCLCHK(ncclCommCount(g->comm, &n));
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
+    return 0;
+}
+
 int gp_comm_destroy(gp_t *g) {
     if (!g) return 0;
     if (g->comm) {

@@ -200,6 +200,8 @@ int gp_acq_lp_argbest(gp_t *gp, int type, double par, double fmin, double y_mean
 int gp_comm_unique_id(char *uid128);
 int gp_comm_init(gp_t *gp, const char *uid128, int rank, int nranks);
 int gp_comm_destroy(gp_t *gp);
+/* rank / size as the RCCL communicator reports them (ncclCommUserRank, ncclCommCount) */
+int gp_comm_info(gp_t *gp, int *rank, int *nranks);
 /* all-gather of one (val, idx) pair per rank: vals[nranks], idxs[nranks]. */
 int gp_comm_allgather_best(gp_t *gp, double val, int64_t idx, double *vals, int64_t *idxs);
 /* the top-k variant ("gather 8 x k pairs"): every rank contributes its k best (val, global idx) pairs

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import cpu_ref as O  # noqa: E402
 from oracle import ref_leaf  # noqa: E402
 
-SIZES = [((64, 2, 32), (0, 1, 2)), ((512, 2, 256), (0,)), ((512, 8, 256), (0,)), ((300, 5, 77), (3,))]
+SIZES = [((64, 2, 32), (0, 1, 2)), ((512, 2, 256), (0, 1, 2)), ((512, 8, 256), (0, 1, 2)), ((300, 5, 77), (3,))]
 KERNELS = [("rbf", False), ("rbf", True), ("Mat52", False), ("Mat52", True)]
 NOISES = [1e-2, 1e-6]
 

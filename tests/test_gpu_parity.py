@@ -3,7 +3,8 @@
 Tolerances (BASELINE.json:north_star): posterior mean / variance within 1e-6 relative, LML within
 1e-8 relative.  Bit-exactness is not expected: the Cholesky, the distance formula and every
 reduction run in a different (blocked / fused) order than LAPACK + NumPy.
-At noise 1e-6 (cond(Ky) ~ 1e8..1e9) solve-dependent quantities are compared at 1e-5.
+At noise 1e-6 (cond(Ky) ~ 1e8..1e9) both the reference's LAPACK result and the HIP result are measured against an
+extended-precision truth (tests/golden/gp_truth.npz) instead of against each other.
 """
 import numpy as np
 import pytest
@@ -30,9 +31,15 @@ def h():
 
 @pytest.mark.parametrize("tag", _tags())
 def test_golden_case(golden, h, tag):
+    """Every golden case against the reference's float64 values at the north-star tolerances (1e-8 LML, 1e-6
+    everything else).  The stress cases (noise 1e-6, cond(Ky) 1e8..1e9) check structure and the LML here; their values
+    are judged against the extended-precision truth in test_stress_case_against_extended_precision_truth, where the
+    reference's own LAPACK result is measured too (comparing two float64 results that each carry cond * eps of error
+    with one another would need tolerances chosen by assertion)."""
     c = Case(golden, tag)
     noise = float(c.noise)
-    tol = 1e-6 if noise >= 1e-4 else 1e-5
+    stress = noise < 1e-4
+    tol = 1e-6
     h.set_data(c.X, c.Y)
     h.set_params(int(c.kernel), int(c.ard), float(c.variance), c.lengthscale, noise)
     K = h.kernel_matrix()
@@ -43,11 +50,22 @@ def test_golden_case(golden, h, tag):
     assert abs(lml - float(c.lml)) <= 1e-8 * abs(float(c.lml))
     assert abs(logdet - float(c.logdet)) <= 1e-10 * abs(float(c.logdet))
     L = h.chol()
+    assert np.all(np.triu(L, 1) == 0)
+    h.set_candidates(c.Xs)
+    Wi = h.woodbury_inv()
+    assert np.array_equal(Wi, Wi.T)
+    f0 = float(c.fmin)
+    acqs = ((_lib.GP_ACQ_EI, 0.01, "EI"), (_lib.GP_ACQ_LCB, 2.0, "LCB"), (_lib.GP_ACQ_MPI, 0.01, "MPI"))
+    for t, par, name in acqs:   # device arg-best == numpy's first extremum of the device's own scores
+        a = h.acq(t, par, f0)
+        for sense, fn in ((-1, np.argmin), (+1, np.argmax)):
+            idx, val = h.acq_argbest(t, par, f0, sense)
+            assert idx == int(fn(a[:, 0])) and val == a[idx, 0]
+    if stress:
+        return
     assert relmax(L[c.rows], c.L_rows) < tol
     assert relmax(np.diag(L), c.L_diag) < tol
-    assert np.all(np.triu(L, 1) == 0)
     assert relmax(h.alpha(), c.alpha) < tol
-    h.set_candidates(c.Xs)
     mu, var = h.predict(True)
     assert relmax(mu, c.mu) < tol
     assert np.max(np.abs(var - c.var) / np.abs(c.var)) < tol
@@ -59,46 +77,110 @@ def test_golden_case(golden, h, tag):
         assert relmax(cov, c.cov_full) < tol
     # gradients of the LML (natural space)
     dv, dl, dn = h.lml_grad(c.lengthscale.size)
-    gtol = 1e-6 if noise >= 1e-4 else 1e-4
     scale = max(abs(float(c.dvariance)), np.max(np.abs(c.dlengthscale)), 1.0)
-    assert abs(dv - float(c.dvariance)) < gtol * scale
-    assert np.max(np.abs(dl - c.dlengthscale)) < gtol * scale
-    assert abs(dn - float(c.dnoise)) < gtol * max(abs(float(c.dnoise)), 1.0)
-    Wi = h.woodbury_inv()
-    assert relmax(Wi[c.rows], c.Wi_rows) < (1e-6 if noise >= 1e-4 else 1e-3)
-    assert np.array_equal(Wi, Wi.T)
-    # predictive gradients, fmin, acquisitions (+ gradients), arg-best
+    assert abs(dv - float(c.dvariance)) < tol * scale
+    assert np.max(np.abs(dl - c.dlengthscale)) < tol * scale
+    assert abs(dn - float(c.dnoise)) < tol * max(abs(float(c.dnoise)), 1.0)
+    assert relmax(Wi[c.rows], c.Wi_rows) < tol
+    # predictive gradients, fmin, acquisitions (+ gradients), the reference's winner
     dm, dvx = h.predict_grad()
     assert relmax(dm, c.dmdx) < tol
-    if noise >= 1e-4:
-        assert relmax(dvx, c.dvdx) < 1e-6
-    else:
-        # stress case: dv/dx* = -2 sum g beta dx cancels to ~1e-6 of its terms (beta = Ky^-1 k*, |Ky^-1| ~ 1e6);
-        # the reference's own value carries cond(Ky) * eps of error, so compare on the prior scale variance / l
-        assert np.max(np.abs(dvx - c.dvdx)) < 1e-7 * float(c.variance) / float(np.min(c.lengthscale))
+    assert relmax(dvx, c.dvdx) < tol
     fmin = h.fmin()
     assert abs(fmin - float(c.fmin)) < tol * max(1.0, abs(float(c.fmin)))
-    f0 = float(c.fmin)
-    for t, par, name in ((_lib.GP_ACQ_EI, 0.01, "EI"), (_lib.GP_ACQ_LCB, 2.0, "LCB"), (_lib.GP_ACQ_MPI, 0.01, "MPI")):
+    for t, par, name in acqs:
         ref = getattr(c, "neg_" + name)
-        a = h.acq(t, par, f0)
-        # stress cases: EI / MPI live ~11 sigma out in the Gaussian tail (u ~ -11), where a 1e-9 relative change of the
-        # mean moves the value by 1e-5..1e-4 -- the reference's own output is no better determined than that
-        atol = (tol if noise >= 1e-4 else 1e-3) * max(np.max(np.abs(ref)), 1e-300)
-        assert np.max(np.abs(a - ref)) <= atol
+        atol = tol * max(np.max(np.abs(ref)), 1e-300)
         a2, da = h.acq_grad(t, par, f0)
-        assert np.max(np.abs(a2 - ref)) <= atol
+        assert np.max(np.abs(h.acq(t, par, f0) - ref)) <= atol and np.max(np.abs(a2 - ref)) <= atol
         dref = getattr(c, "neg_d" + name)
-        # stress cases inherit the ds/dx cancellation error above (relative 1e-4..1e-3 of a ~1e-6 quantity)
-        assert np.max(np.abs(da - dref)) <= (1e-5 if noise >= 1e-4 else 2e-3) * max(np.max(np.abs(dref)), 1e-300)
-        idx, val = h.acq_argbest(t, par, f0, -1)
-        ia = int(np.argmin(a[:, 0]))
-        assert idx == ia and val == a[ia, 0]
-        # same winner as the reference unless the top two are closer than the tolerance
-        ir = int(getattr(c, "argmin_" + name))
+        assert np.max(np.abs(da - dref)) <= 1e-5 * max(np.max(np.abs(dref)), 1e-300)   # d/dx of a tail probability
+        idx, _ = h.acq_argbest(t, par, f0, -1)
+        ir = int(getattr(c, "argmin_" + name))   # same winner as the reference unless the top two are within tolerance
         assert idx == ir or abs(ref[idx, 0] - ref[ir, 0]) <= 2 * atol
-        idx2, val2 = h.acq_argbest(t, par, f0, +1)
-        assert idx2 == int(np.argmax(a[:, 0])) and val2 == a[idx2, 0]
+
+
+def _truth_tags():
+    import os
+    t = np.load(os.path.join(os.path.dirname(__file__), "golden", "gp_truth.npz"))
+    return sorted({k.split("/")[0] for k in t.files})
+
+
+@pytest.mark.parametrize("tag", _truth_tags())
+def test_stress_case_against_extended_precision_truth(golden, h, tag):
+    """noise = 1e-6 (cond(Ky) 1e8..1e9): the comparisons of test_golden_case at 1e-5 .. 2e-3 are between TWO float64
+    results that both carry cond * eps of error.  Here both are measured against tests/golden/gp_truth.npz (the same
+    formulas on the same inputs in 80-bit arithmetic, generate_truth.py; itself within 2e-13 of 60-digit arithmetic)
+    and the HIP result has to be as close to the truth as the north-star tolerance (1e-8 LML, 1e-6 everything else) OR
+    as close as the reference's own LAPACK path gets -- within a factor 4, since the blocked factorisation with
+    inverted tiles has other error constants than LAPACK's substitutions.  Measured errors are written to
+    gpurun_out/stress_truth.json for DESIGN.md."""
+    import json
+    import os
+    T = np.load(os.path.join(os.path.dirname(__file__), "golden", "gp_truth.npz"))
+    t = Case(T, tag)
+    c = Case(golden, tag)
+    noise = float(c.noise)
+    assert noise == 1e-6
+    h.set_data(c.X, c.Y)
+    h.set_params(int(c.kernel), int(c.ard), float(c.variance), c.lengthscale, noise)
+    lml, logdet, jit = h.fit()
+    assert jit == 0.0
+    h.set_candidates(c.Xs)
+    mu, var = h.predict(True)
+    _, var0 = h.predict(False)
+    dv, dl, dn = h.lml_grad(c.lengthscale.size)
+    Wi = h.woodbury_inv()
+    dm, dvx = h.predict_grad()
+    fmin = h.fmin()
+    f0 = float(t.fmin)
+    acq = {}
+    for typ, par, name in ((_lib.GP_ACQ_EI, 0.01, "EI"), (_lib.GP_ACQ_LCB, 2.0, "LCB"), (_lib.GP_ACQ_MPI, 0.01, "MPI")):
+        acq[name] = h.acq_grad(typ, par, f0)
+
+    def sc(x):
+        return max(float(np.max(np.abs(x))), 1e-300)
+    vscale = float(c.variance)
+    gscale = max(abs(float(t.dvariance)), sc(t.dlengthscale), 1.0)
+    # (name, hip, reference (golden through LAPACK), truth, scale the error is relative to, north-star tolerance)
+    rows = [
+        ("lml", lml, float(c.lml), float(t.lml), abs(float(t.lml)), 1e-8),
+        ("logdet", logdet, float(c.logdet), float(t.logdet), abs(float(t.logdet)), 1e-8),
+        ("alpha", h.alpha(), c.alpha, t.alpha, sc(t.alpha), 1e-6),
+        ("L_diag", np.diag(h.chol()), c.L_diag, t.L_diag, sc(t.L_diag), 1e-6),
+        ("mean", mu, c.mu, t.mu, sc(t.mu), 1e-6),
+        ("var", var / t.var, c.var / t.var, t.var / t.var, 1.0, 1e-6),
+        ("var_noiseless", var0, c.var_noiseless, t.var_noiseless, vscale, 1e-6),
+        ("dvariance", dv, float(c.dvariance), float(t.dvariance), gscale, 1e-6),
+        ("dlengthscale", dl, c.dlengthscale, t.dlengthscale, gscale, 1e-6),
+        ("dnoise", dn, float(c.dnoise), float(t.dnoise), max(abs(float(t.dnoise)), 1.0), 1e-6),
+        ("Wi_rows", Wi[c.rows], c.Wi_rows, t.Wi_rows, float(t.Wi_absmax), 1e-6),
+        ("dmdx", dm, c.dmdx, t.dmdx, sc(t.dmdx), 1e-6),
+        ("dvdx", dvx, c.dvdx, t.dvdx, vscale / float(np.min(c.lengthscale)), 1e-6),
+        ("fmin", fmin, float(c.fmin), float(t.fmin), max(1.0, abs(float(t.fmin))), 1e-6),
+    ]
+    for name in ("EI", "LCB", "MPI"):
+        rows.append(("neg_" + name, acq[name][0], getattr(c, "neg_" + name), getattr(t, "neg_" + name),
+                     sc(getattr(t, "neg_" + name)), 1e-6))
+        rows.append(("neg_d" + name, acq[name][1], getattr(c, "neg_d" + name), getattr(t, "neg_d" + name),
+                     sc(getattr(t, "neg_d" + name)), 1e-6))
+    report, bad = {}, []
+    for name, hip, ref, truth, scale, tol in rows:
+        e_hip = float(np.max(np.abs(np.asarray(hip, dtype=float) - truth))) / scale
+        e_ref = float(np.max(np.abs(np.asarray(ref, dtype=float) - truth))) / scale
+        report[name] = {"hip": e_hip, "lapack_reference": e_ref, "north_star_tol": tol}
+        if not e_hip <= max(tol, 4.0 * e_ref):
+            bad.append((name, e_hip, e_ref))
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "stress_truth.json")
+        allr = json.load(open(path)) if os.path.exists(path) else {}
+        allr[tag] = report
+        json.dump(allr, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    assert not bad, bad
 
 
 def test_multi_output_with_normalizer(golden):

@@ -1,0 +1,228 @@
+"""GPU: entry points added in round 2 -- top-k anchors, dL_dK, device-side posterior samples, the broadcast of the fit's
+host scalars, and the ordered library shutdown.  All through the C ABI (ctypes)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import gaussian_process_optimization_amd as gpo
+from conftest import Case
+from gaussian_process_optimization_amd import _lib
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def h():
+    hd = _lib.Handle(0)
+    yield hd
+    hd.close()
+
+
+@pytest.mark.parametrize("M,k", [(3000, 5), (40, 64), (3, 5), (129, 1)])
+def test_topk_equals_stable_argsort(h, M, k):
+    """AnchorPointsGenerator.get keeps argsort(scores)[:num_anchor] (anchor_points_generator.py:59-61)."""
+    rng = np.random.default_rng(M + k)
+    X = rng.uniform(0, 1, (60, 2)); Y = rng.standard_normal((60, 1))
+    h.set_data(X, Y)
+    h.set_params(0, 0, 1.0, [0.4], 0.1)
+    h.fit()
+    Xs = rng.uniform(0, 1, (M, 2))
+    if M >= 40:   # exact ties, also among the winners (duplicates of what will be the best row are appended below)
+        Xs[M // 2] = Xs[3]
+        Xs[M - 1] = Xs[3]
+    h.set_candidates(Xs)
+    fmin = h.fmin()
+    for typ, par in ((_lib.GP_ACQ_EI, 0.01), (_lib.GP_ACQ_LCB, 2.0), (_lib.GP_ACQ_MPI, 0.01)):
+        a = h.acq(typ, par, fmin)[:, 0]
+        if M >= 40:
+            best = int(np.argmin(a))
+            Xt = Xs.copy()
+            Xt[(best + 7) % M] = Xt[best]          # the winner has a twin
+            h.set_candidates(Xt)
+            a = h.acq(typ, par, fmin)[:, 0]
+        for sense in (-1, +1):
+            idx, val = h.acq_topk(typ, par, fmin, sense, k)
+            order = np.argsort(a if sense < 0 else -a, kind="stable")[:k]
+            n = order.size
+            assert np.array_equal(idx[:n], order) and np.array_equal(val[:n], a[order])
+            assert (idx[n:] == -1).all()
+        h.set_candidates(Xs)
+    with pytest.raises(ValueError):
+        h.acq_topk(_lib.GP_ACQ_EI, 0.01, fmin, -1, 65)
+
+
+def test_acquisition_topk_host_mirror():
+    X, Y, Xs = O.synthetic_problem(200, 2, 700, seed=3)
+    gm = gpo.GPModel(kernel=gpo.kern.RBF(2, 1.0, 0.4), noise_var=1e-2, max_iters=0, verbose=False)
+    gm.updateModel(X, Y, None, None)
+    acq = gpo.AcquisitionEI(gm, jitter=0.01)
+    a = acq.acquisition_function(Xs)[:, 0]
+    idx, val = acq.topk(Xs, 5, -1)
+    order = np.argsort(a, kind="stable")[:5]
+    assert np.array_equal(idx, order) and np.array_equal(val, a[order])
+    i, v = acq.argbest(Xs, -1)
+    assert i == idx[0] and v == val[0]
+
+
+@pytest.mark.parametrize("tag", ["N64_D2_M32_s1_rbf_ard_n0.01", "N64_D2_M32_s2_Mat52_iso_n0.01",
+                                 "N512_D8_M256_s1_Mat52_ard_n0.01", "N300_D5_M77_s3_rbf_iso_n0.01"])
+def test_dl_dk_feeds_the_reference_side_kernel_gradients(golden, h, tag):
+    """gp_get_dl_dk is what grad_dict['dL_dK'] carries (exact_gaussian_inference.py:70,74): pushed through the
+    oracle's Stationary.update_gradients_full / Gaussian.exact_inference_gradients (stationary.py:218-238,
+    gaussian.py:78-79 -- the host-side consumers of an unmodified GPy) it reproduces the golden gradients."""
+    c = Case(golden, tag)
+    h.set_data(c.X, c.Y)
+    h.set_params(int(c.kernel), int(c.ard), float(c.variance), c.lengthscale, float(c.noise))
+    h.fit()
+    G = h.dL_dK()
+    assert np.array_equal(G, G.T)
+    kern = O.make_kernel("rbf" if int(c.kernel) == 0 else "Mat52", c.X.shape[1], float(c.variance), c.lengthscale,
+                         ARD=bool(int(c.ard)))
+    dvar, dlen = kern.update_gradients_full(G, c.X)
+    scale = max(abs(float(c.dvariance)), float(np.max(np.abs(c.dlengthscale))), 1.0)
+    assert abs(dvar - float(c.dvariance)) < 1e-6 * scale
+    assert np.max(np.abs(np.atleast_1d(dlen) - c.dlengthscale)) < 1e-6 * scale
+    assert abs(np.trace(G) - float(c.dnoise)) < 1e-6 * max(abs(float(c.dnoise)), 1.0)
+    # and entry by entry: 0.5 (alpha alpha^T - Ky^-1) from the oracle's posterior
+    p = O.exact_gaussian_inference(kern, c.X, c.Y, float(c.noise))
+    G0 = 0.5 * (p["alpha"] @ p["alpha"].T - p["Wi"])
+    assert np.max(np.abs(G - G0)) <= 1e-6 * np.max(np.abs(G0))
+    # the device's own reduction of the same matrix
+    dv, dl, dn = h.lml_grad(c.lengthscale.size)
+    assert abs(dv - dvar) < 1e-9 * scale and np.max(np.abs(dl - np.atleast_1d(dlen))) < 1e-9 * scale
+
+
+@pytest.mark.parametrize("M,noise_in", [(200, True), (77, False), (300, True)])
+def test_posterior_samples_factor_reproduces_the_covariance(h, M, noise_in):
+    """gp_posterior_samples (gp.py:581-609): with Z = I the deviations are the columns of the factor C; C is lower
+    triangular, C C^T equals the device's full covariance (posterior.py:280-284), and for a well-conditioned
+    covariance (noise included) C equals the oracle's Cholesky factor of the oracle's covariance."""
+    X, Y, Xs = O.synthetic_problem(400, 3, M, seed=M)
+    kern = O.Matern52(3, 1.2, 0.6)
+    gp = O.OracleGP(X, Y, kern, 0.05)
+    h.set_data(X, Y)
+    h.set_params(1, 0, 1.2, [0.6], 0.05)
+    h.fit()
+    h.set_candidates(Xs)
+    mean, dev, jit = h.posterior_samples(np.eye(M), include_noise=noise_in)
+    C = dev.T                                   # dev[s, :] = C e_s
+    assert np.all(np.triu(C, 1) == 0)
+    m1, cov = h.predict_full_cov(noise_in)
+    assert np.array_equal(mean, m1)
+    R = C @ C.T - cov - jit * np.eye(M)
+    assert np.max(np.abs(R)) <= 1e-12 * np.max(np.abs(cov))
+    mu0, cov0 = gp.predict(Xs, full_cov=True, include_likelihood=noise_in)
+    assert np.max(np.abs(mean - mu0)) <= 1e-6 * np.max(np.abs(mu0))
+    if noise_in:
+        assert jit == 0.0
+        C0 = np.linalg.cholesky(cov0)
+        assert np.max(np.abs(C - C0)) <= 1e-6 * np.max(np.abs(C0))
+        # fixed normals: the draws themselves
+        Z = np.random.default_rng(1).standard_normal((4, M))
+        _, d4, _ = h.posterior_samples(Z, include_noise=True)
+        assert np.max(np.abs(d4 - Z @ C0.T)) <= 1e-6 * np.max(np.abs(Z @ C0.T))
+
+
+def test_posterior_samples_jitter_ladder_on_a_singular_covariance(h):
+    """Duplicated prediction points make the noiseless posterior covariance exactly singular: jitchol's ladder
+    (linalg.py:62-75) kicks in, as it does for GPy's own sampling paths."""
+    X, Y, Xs = O.synthetic_problem(150, 2, 40, seed=8)
+    Xs[20:] = Xs[:20]
+    h.set_data(X, Y)
+    h.set_params(0, 0, 1.0, [0.5], 0.01)
+    h.fit()
+    h.set_candidates(Xs)
+    mean, dev, jit = h.posterior_samples(np.eye(40), include_noise=False)
+    assert jit > 0.0 and np.isfinite(dev).all()
+    _, cov = h.predict_full_cov(False)
+    C = dev.T
+    assert np.max(np.abs(C @ C.T - cov - jit * np.eye(40))) <= 1e-10 * np.max(np.abs(cov))
+    # the ladder's first rung is mean(diag) * 1e-6 with the prior variance as the diagonal bound
+    assert jit in [1.0 * 1e-6 * 10 ** k for k in range(6)] or jit == pytest.approx(1e-6, rel=1e-9) or jit > 1e-6
+
+
+def test_posterior_samples_f_host_mirror():
+    """GPRegression.posterior_samples_f: shape [Nnew, output_dim, size] (gp.py:589), reproducible with given normals,
+    the normaliser undone (gp.py:594-595), and the sample mean / spread follow the posterior."""
+    rng = np.random.default_rng(4)
+    X = rng.uniform(0, 1, (120, 2))
+    Y = np.c_[np.sin(4 * X[:, 0]) + 3.0, 10 * np.cos(3 * X[:, 1])] + 0.05 * rng.standard_normal((120, 2))
+    Xs = rng.uniform(0, 1, (30, 2))
+    m = gpo.models.GPRegression(X, Y, gpo.kern.RBF(2, 1.0, 0.4), noise_var=0.01, normalizer=True)
+    Z = rng.standard_normal((2, 5, 30))
+    f1 = m.posterior_samples_f(Xs, size=5, normals=Z)
+    f2 = m.posterior_samples_f(Xs, size=5, normals=Z)
+    assert f1.shape == (30, 2, 5) and np.array_equal(f1, f2)
+    mu, cov = m._raw_predict(Xs, full_cov=True)
+    std = np.asarray(m.normalizer.std)
+    mean_nat = m.normalizer.inverse_mean(mu)
+    C = np.linalg.cholesky(cov + 1e-10 * np.eye(30))
+    for d in range(2):
+        ref = mean_nat[:, d:d + 1] + std[d] * (C @ Z[d].T)
+        assert np.max(np.abs(f1[:, d, :] - ref)) <= 1e-5 * np.max(np.abs(ref))
+    big = m.posterior_samples_f(Xs, size=4000)
+    assert big.shape == (30, 2, 4000)
+    sd = np.sqrt(np.clip(np.diag(cov), 0, None))
+    for d in range(2):
+        err = np.abs(big[:, d, :].mean(1) - mean_nat[:, d])
+        assert (err <= 5 * std[d] * sd / np.sqrt(4000) + 1e-6).all()
+    m.close()
+
+
+def test_bcast_fit_carries_the_host_scalars(golden):
+    """gp_comm_bcast_fit moves jitter / LML / log det with the factor (one-rank communicator: what a 1-GPU box can
+    run; the receiver-side assignment is the same code path): after the broadcast of a fit that needed jitter the
+    context reports the root's scalars and gp_fmin uses the root's jitter (y - (noise + 1e-8 + jitter) alpha)."""
+    h = _lib.Handle(0)
+    h.set_data(golden["jit3/X"], golden["jit3/Y"])
+    h.set_params(_lib.GP_KERNEL_RBF, 0, 1.0, [0.5], float(golden["jit3/noise"]))
+    lml, logdet, jit = h.fit(5)
+    assert jit > 0
+    f0 = h.fmin()
+    h.comm_init(h.comm_unique_id(), 0, 1)
+    h.comm_bcast_fit(0)
+    assert h.fit_state() == (lml, logdet, jit)
+    assert h.fmin() == f0
+    with pytest.raises(ValueError):
+        h.comm_bcast_fit(3)
+    # top-k gather with one rank: identity
+    v = np.array([0.5, -1.0, 2.0]); i = np.array([7, 3, -1], dtype=np.int64)
+    av, ai = h.comm_allgather_topk(v, i, 1)
+    assert np.array_equal(av, v) and np.array_equal(ai, i)
+    h.lib.gp_comm_destroy(h.h)
+    h.close()
+
+
+def test_ordered_shutdown_in_a_fresh_process():
+    """gp_shutdown: streams and events are destroyed in order, live contexts turn into GP_ERR_STATE, gp_destroy still
+    works, a new context can be created afterwards, and the process exits 0 (also without an explicit shutdown: the
+    atexit hook).  Run in a child process so that this session's stream set is left alone."""
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from gaussian_process_optimization_amd import _lib
+h = _lib.Handle(0)
+X = np.random.default_rng(0).uniform(0, 1, (700, 3)); Y = np.sin(X.sum(1, keepdims=True))
+h.set_data(X, Y); h.set_params(0, 0, 1.0, [0.5], 1e-2); h.set_candidates(X[:200])
+h.fit_predict(True)
+lml = h.fit()[0]
+assert h.lib.gp_shutdown() == 0
+try:
+    h.fit(); raise SystemExit("fit after shutdown must fail")
+except RuntimeError as e:
+    assert "shut down" in str(e), e
+h.close()
+h2 = _lib.Handle(0)            # the stream set is rebuilt on demand
+h2.set_data(X, Y); h2.set_params(0, 0, 1.0, [0.5], 1e-2)
+assert h2.fit()[0] == lml
+keep_alive = _lib.Handle(0)    # never closed: the atexit hook has to cope with a live context
+print("shutdown ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "shutdown ok" in r.stdout

@@ -148,6 +148,13 @@ struct gp_ctx {
     int rank = 0, nranks = 1;
     double *dComm = nullptr;  // gather scratch of the top-k exchange
     long capComm = 0;
+    // fp64 emulation on the int8 matrix cores (rns.hip), candidate solve only
+    int emulate_fp64 = 0;
+    int rns_pair = 1;  // two panels per residue launch
+    signed char *dLr = nullptr, *dSr = nullptr, *dRr = nullptr;  // residue planes of L, of the current S panel, accumulator
+    long capLr = 0, capSr = 0, capRr = 0;
+    bool lr_valid = false;
+    int lr_W = 0;
     bool dead = false;  // gp_shutdown ran: the device's streams are gone, only gp_destroy is still valid
 };
 
@@ -465,6 +472,8 @@ int gp_destroy(gp_t *g) {
         if (p) hipFree(p);
     if (g->dInfo) hipFree(g->dInfo);
     if (g->dRedI) hipFree(g->dRedI);
+    for (signed char *p : {g->dLr, g->dSr, g->dRr})
+        if (p) hipFree(p);
     for (auto &kv : g->tile_lists) hipFree(kv.second);
     // events recorded on the shared streams go first; the streams themselves belong to the per-device set shared by
     // every context of the process and are destroyed by gp_shutdown / the exit hook
@@ -532,6 +541,11 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->trsm_rows64 = (int)value;
     } else if (!strcmp(name, "trsm_waves8")) {
         g->trsm_waves8 = (int)value;
+    } else if (!strcmp(name, "rns_pair")) {
+        g->rns_pair = value ? 1 : 0;
+    } else if (!strcmp(name, "emulate_fp64")) {
+        g->emulate_fp64 = value ? 1 : 0;
+        g->predicted = false;
     } else if (!strcmp(name, "mc_max")) {
         if (value < GP_TILE) return fail(GP_ERR_ARG, "mc_max < 128");
         g->mc_max = round_up(value, GP_TILE);
@@ -590,6 +604,7 @@ int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N, int D, int
     g->fmin_valid = false;
     g->wi_valid = false;
     g->invp_valid = false;
+    g->lr_valid = false;
     g->predicted = false;
     g->kp.D = D;
     return 0;
@@ -614,6 +629,7 @@ int gp_set_gower(gp_t *g, int enable, const int *is_discrete, const double *rang
     g->fmin_valid = false;
     g->wi_valid = false;
     g->invp_valid = false;
+    g->lr_valid = false;
     g->predicted = false;
     return 0;
 }
@@ -634,6 +650,7 @@ int gp_set_params(gp_t *g, int kernel, int ard, double variance, const double *l
     g->fmin_valid = false;
     g->wi_valid = false;
     g->invp_valid = false;
+    g->lr_valid = false;
     g->predicted = false;
     return 0;
 }
@@ -922,6 +939,116 @@ static void solve_rows(gp_ctx *g, double *T, double *S, int mt, int trapezoid, i
     }
 }
 
+static int byte_realloc(signed char **p, long *cap, long need) {
+    if (need <= *cap && *p) return 0;
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void **)p, (size_t)need);
+    if (e != hipSuccess) return fail(GP_ERR_HIP, "hipMalloc(%ld bytes) -> %s", need, hipGetErrorString(e));
+    *cap = need;
+    return 0;
+}
+
+// The candidate solve S = T L^-T with the running right-hand side's updates  T[:, > J] -= S_J L[> J, J]^T  carried in
+// residue form on the int8 matrix cores (rns.hip; option "emulate_fp64").  Per panel J: the fp64 columns of T are
+// rebuilt from the exact integer accumulator, S_J = T_J invP_J^T runs in fp64 as before (5 % of the flops), S_J is
+// converted to residues and ONE int8 launch (16 moduli) applies it to every column to the right.
+static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
+    const long Npad = g->Npad, lda = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    const int W = g->invp_W;
+    const long PB = (long)W * GP_TILE, Mcpad = (long)mt * GP_TILE;
+    if (PB > 896) return fail(GP_ERR_ARG, "emulate_fp64 needs panel_tiles <= 7 (int32 sums must stay below 2^24)");
+    if (g->N > (1L << 20)) return fail(GP_ERR_ARG, "emulate_fp64 needs N <= 2^20");
+    int rc;
+    if (rns_init_constants(g->device)) return fail(GP_ERR_HIP, "rns constants");
+    // 256 x 256 workgroup tiles: rows / columns padded to multiples of 256 (zero residues in the padding)
+    const long Mc256 = round_up(Mcpad, 256), Lrows = round_up(Npad, 256);
+    const int mt256 = (int)(Mc256 / 256), nt256 = (int)(Lrows / 256);
+    const long KS = 2 * PB;   // up to two panels of S side by side (one launch then contracts both)
+    auto zalloc = [&](signed char **p, long *cap, long need) -> int {
+        if (need <= *cap && *p) return 0;
+        int r = byte_realloc(p, cap, need);
+        if (r) return r;
+        if (hipMemsetAsync(*p, 0, (size_t)need, g->s) != hipSuccess) return fail(GP_ERR_HIP, "hipMemsetAsync");
+        g->lr_valid = false;
+        return 0;
+    };
+    if ((rc = zalloc(&g->dLr, &g->capLr, (long)GP_RNS_T * Lrows * Npad))) return rc;
+    if ((rc = zalloc(&g->dSr, &g->capSr, (long)GP_RNS_T * Mc256 * KS))) return rc;
+    if ((rc = zalloc(&g->dRr, &g->capRr, (long)GP_RNS_T * mt256 * nt256 * 65536))) return rc;
+    hipStream_t s = g->s;
+    int *flag = g->dInfo + 2;
+    HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), s));
+    // common power-of-two scale: |L_ij| <= sqrt(max diag of Ky), |S_ik| <= sqrt(prior variance); one spare bit
+    const double diag0 = (g->kp.gower ? std::pow(g->kp.variance, g->D) : g->kp.variance) + g->noise + 1e-8 + g->jitter;
+    int e = 1 + (int)std::ceil(std::log2(std::sqrt(std::max(diag0, 1e-300))));
+    if (e < 0) e = 0;
+    const double scale = std::ldexp(1.0, 52 - e), back = std::ldexp(1.0, 2 * e);
+    const long Lplane = Lrows * Npad, Splane = Mc256 * KS;
+    if (!g->lr_valid || g->lr_W != W) {   // residues of L, panel by panel (rows strictly below each diagonal panel block)
+        for (int J0 = 0; J0 < nt; J0 += W) {
+            const int J1 = std::min(J0 + W, nt);
+            if (J1 >= nt) break;
+            launch_rns_convert(s, g->dA + (long)J1 * GP_TILE * lda + (long)J0 * GP_TILE, lda, Npad - (long)J1 * GP_TILE,
+                               (long)(J1 - J0) * GP_TILE, g->dLr + (long)J1 * GP_TILE * Npad + (long)J0 * GP_TILE, Lplane,
+                               Npad, scale, flag);
+        }
+        g->lr_valid = true;
+        g->lr_W = W;
+    }
+    // Panels are taken in pairs (J, J+1): panel J+1's columns receive panel J's update as a small launch of their own,
+    // then ONE launch contracts both panels (K = 2 PB, an exact reduction mod p between the halves) into every column
+    // further right -- half the round trips of the residue accumulator through HBM.
+    const int pair = g->rns_pair;
+    bool first = true;
+    for (int J0 = 0, J = 0; J0 < nt;) {
+        const int J1 = std::min(J0 + W, nt), J2 = std::min(J1 + W, nt);
+        const int K0 = (J1 - J0) * GP_TILE, K1 = (J2 - J1) * GP_TILE;
+        auto panel_solve = [&](int Ja, int Jb, int Jidx) {   // S[:, Ja..Jb) = T[:, Ja..Jb) invP^T, fp64
+            GemmOpt o;
+            o.k_end_tri = 1;
+            o.b_sub = Ja;
+            gemm(g, s, 0, S, Npad, T + (long)Ja * GP_TILE, Npad, g->dInvP + (long)Jidx * PB * PB, PB, 1, (Jb - Ja) * GP_TILE,
+                 TileSet{0, mt, Ja, Jb, 0}, o);
+        };
+        if (!first) launch_rns_reconstruct256(s, g->dRr, mt256, nt256, mt256, J0, J1, Mcpad, T, Npad, back);
+        panel_solve(J0, J1, J);
+        if (J1 >= nt) break;
+        launch_rns_convert(s, S + (long)J0 * GP_TILE, Npad, Mcpad, K0, g->dSr, Splane, KS, scale, flag);
+        const bool two = pair && J2 > J1 && J2 < nt;
+        if (!two) {
+            launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, Npad, Lplane, g->dRr, mt256, nt256, mt256,
+                               J1 / 2, nt256, K0, K0, first ? 1 : 0);
+            first = false;
+            J0 = J1;
+            ++J;
+            continue;
+        }
+        // panel J -> the columns of panel J+1 only (256-column tiles that overlap [J1, J2))
+        launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, Npad, Lplane, g->dRr, mt256, nt256, mt256,
+                           J1 / 2, (J2 + 1) / 2, K0, K0, first ? 1 : 0);
+        launch_rns_reconstruct256(s, g->dRr, mt256, nt256, mt256, J1, J2, Mcpad, T, Npad, back);
+        panel_solve(J1, J2, J + 1);
+        launch_rns_convert(s, S + (long)J1 * GP_TILE, Npad, Mcpad, K1, g->dSr + K0, Splane, KS, scale, flag);
+        // both panels -> every column right of panel J+1.  The tile column that straddles J2 (odd J2) already holds
+        // panel J's update in its left half from the small launch: those columns are final and never read again, its
+        // right half must not get panel J twice -- so the small launch stops at the tile boundary below J2 and this
+        // one starts there when J2 is odd.
+        launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, Npad, Lplane, g->dRr, mt256, nt256, mt256,
+                           (J2 + 1) / 2, nt256, K0 + K1, K0, first ? 1 : 0);
+        first = false;
+        J0 = J2;
+        J += 2;
+    }
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (bad) return fail(GP_ERR_STATE, "emulate_fp64: an operand left the fixed-point range (non-finite or > 2^%d)", e);
+    return 0;
+}
+
 __global__ void dot_ay_kernel(const double *alpha, long lda_, const double *Y, long N, int P, double *out) {
     __shared__ double sh[16];
     const int p = blockIdx.x;
@@ -992,6 +1119,7 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     g->fmin_valid = false;
     g->wi_valid = false;
     g->invp_valid = false;
+    g->lr_valid = false;
     g->predicted = false;
 
     double jitter = 0.0;
@@ -1137,7 +1265,8 @@ int gp_fit_predict(gp_t *g, int maxtries, int include_noise, double *lml, double
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     HIPCHK(hipSetDevice(g->device));
     const int nt = (int)(g->Npad / GP_TILE);
-    const bool can_pipe = g->lookahead && nt > g->panel_tiles && round_up(g->M, GP_TILE) <= g->mc_max;
+    // the emulated candidate solve runs after the factorisation (its residue planes of L need the complete factor)
+    const bool can_pipe = g->lookahead && nt > g->panel_tiles && round_up(g->M, GP_TILE) <= g->mc_max && !g->emulate_fp64;
     int rc;
     if (can_pipe) {
         if ((rc = fit_impl(g, maxtries, 1, include_noise))) return rc;
@@ -1193,6 +1322,7 @@ int gp_kernel_matrix(gp_t *g, double *K) {
     g->fitted = false;  // dA was overwritten
     g->wi_valid = false;
     g->invp_valid = false;
+    g->lr_valid = false;
     g->predicted = false;
     return 0;
 }
@@ -1231,8 +1361,12 @@ static int run_predict(gp_ctx *g, int include_noise) {
         int ph = phase_begin(g, "cross_k", 0.0, 8.0 * (double)(N + mc) * g->D + 8.0 * (double)N * mc);
         launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, g->N, Npad, g->kp);
         phase_end(g, ph);
-        ph = phase_begin(g, "cand_solve", (double)N * N * mc, 0.0);
-        solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), 0);
+        ph = phase_begin(g, g->emulate_fp64 ? "cand_solve_emulated" : "cand_solve", (double)N * N * mc, 0.0);
+        if (g->emulate_fp64) {
+            if ((rc = solve_rows_rns(g, g->dT, g->dT2, (int)(mcpad / GP_TILE)))) return rc;
+        } else {
+            solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), 0);
+        }
         phase_end(g, ph);
         ph = phase_begin(g, "reduce", 0.0, 8.0 * (double)N * mc);
         launch_predict_reduce(g->s, g->dT2, Npad, mc, N, g->dA + Npad * Npad, Npad, P, g->kp.variance,
@@ -1615,6 +1749,7 @@ int gp_comm_bcast_fit(gp_t *g, int root) {
     g->fmin_valid = false;
     g->wi_valid = false;
     g->invp_valid = false;
+    g->lr_valid = false;
     g->predicted = false;
     return 0;
 }

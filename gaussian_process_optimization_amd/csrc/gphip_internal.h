@@ -136,3 +136,14 @@ void launch_dldk(hipStream_t s, double *out, long ldo, const double *alpha, long
                  long ldw, long N);
 // zero the strict upper triangle of the nt diagonal 128-tiles (the factor's tiles keep the symmetric input there)
 void launch_zero_upper_diag(hipStream_t s, double *A, long lda, int nt);
+
+// ---- rns.hip: fp64-equivalent contraction on the int8 matrix cores (option "emulate_fp64") -----------------------------
+#define GP_RNS_T 16
+int rns_init_constants(int device);
+void launch_rns_convert(hipStream_t s, const double *src, long ld, long rows, long cols, signed char *dst,
+                        long plane_stride, long ldd, double scale, int *flag);
+void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
+                        long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int kpanel,
+                        int first);
+void launch_rns_reconstruct256(hipStream_t s, const signed char *R, int mt_all, int nt_all, int mt, int c0_128, int c1_128,
+                               long rows, double *T, long ldt, double scale_2e);

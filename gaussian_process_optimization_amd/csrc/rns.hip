@@ -1,0 +1,382 @@
+// fp64-equivalent contraction on the int8 matrix cores ("emulate_fp64", default OFF; prototype for the candidate solve).
+//
+// Why: the dense contractions of the path are bound by the fp64 MFMA rate (v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s peak), the
+// int8 MFMA (v_mfma_i32_32x32x32_i8) runs at 64x that rate with EXACT int32 accumulation.  Scheme (Ozaki scheme II --
+// integer modular emulation of matrix multiplication -- re-arranged so that the accumulator stays in residue form across
+// all panel updates and is reconstructed once per column; model and constants: tools/rns_model.py):
+//   * operands |x| < 2^e are fixed-point integers v = rint(x 2^(52-e)) (exact in fp64), stored as their symmetric residues
+//     v mod p_l (int8) for 16 pairwise coprime moduli p_l <= 253, P = prod p_l ~ 2^125.1;
+//   * T[:, c] -= sum_J S_J L[c, J]^T (the running right-hand side of dtrtrs, posterior.py:294) becomes, per modulus, an int8
+//     GEMM whose int32 sums are reduced mod p_l and added to an int8 residue accumulator R_l -- no rounding anywhere;
+//   * before panel c of T is needed in fp64 (for the product with the inverted diagonal panel) the exact integer
+//     X = sum a b (|X| < N 2^104 < P/2) is recovered from its 16 residues by the CRT in fraction form,
+//     X / P = centred_frac(sum_l w_l / p_l), w_l = r_l q_l mod p_l, with two fp64 accumulators (terms rounded to
+//     multiples of 2^-44 sum exactly; the remainders carry a double-double reciprocal), and T -= X 2^(2e-104).
+// The only approximation is the fixed-point rounding of the operands: absolute 2^(e-53) per entry, i.e. one fp64 ulp of
+// the largest entries -- the same backward error an fp64 product commits.
+//
+// Reference call site of the contraction: LAPACK dtrtrs, GPy/GPy/inference/latent_function_inference/posterior.py:294.
+#include "gphip_internal.h"
+
+typedef int int4_t __attribute__((ext_vector_type(4)));
+typedef int int16v_t __attribute__((ext_vector_type(16)));
+
+#define RNS_T 16
+// K bytes per stage BKB = 128 or 64; LDS row pitch BKB + 16 bytes (conflict-free ds_read_b128 over the rows of a lane group)
+
+struct RnsConst {
+    float p[RNS_T], inv_p[RNS_T];
+    int q[RNS_T];
+    double pd[RNS_T], inv_pd[RNS_T], ih[RNS_T], il[RNS_T];
+    double P_scaled;  // P * 2^-104
+};
+__constant__ RnsConst c_rns;
+
+// pairwise coprime, all <= 253: a quotient that is off by one near a half-way case still leaves |remainder| <= 127, so the
+// symmetric residues need no fix-up step (0.505 * 253 < 128)
+static const int h_moduli[RNS_T] = {253, 251, 249, 247, 245, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193, 191};
+
+static bool g_rns_const_done[64] = {false};
+int rns_init_constants(int device) {
+    if (device < 0 || device >= 64) return -1;
+    if (g_rns_const_done[device]) return 0;
+    RnsConst h;
+    // P and q_l = (P / p_l)^-1 mod p_l in 128-bit integer arithmetic
+    unsigned __int128 P = 1;
+    for (int l = 0; l < RNS_T; ++l) P *= (unsigned)h_moduli[l];
+    for (int l = 0; l < RNS_T; ++l) {
+        const int p = h_moduli[l];
+        unsigned __int128 Pl = P / (unsigned)p;
+        const int r = (int)(Pl % (unsigned)p);
+        int inv = 0;
+        for (int x = 1; x < p; ++x)
+            if ((r * x) % p == 1) {
+                inv = x;
+                break;
+            }
+        h.q[l] = inv;
+        h.p[l] = (float)p;
+        h.inv_p[l] = 1.0f / (float)p;
+        h.pd[l] = (double)p;
+        h.inv_pd[l] = 1.0 / (double)p;
+        h.ih[l] = 1.0 / (double)p;
+        // il = 1/p - ih exactly enough: one Newton residual in long double (64-bit mantissa) is below 2^-106 relative
+        const long double res = (1.0L - (long double)h.ih[l] * (long double)p) / (long double)p;
+        h.il[l] = (double)res;
+    }
+    long double Pl = 1.0L;
+    for (int l = 0; l < RNS_T; ++l) Pl *= (long double)h_moduli[l];
+    h.P_scaled = (double)(Pl * 0x1p-104L);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_rns), &h, sizeof h) != hipSuccess) return -1;
+    g_rns_const_done[device] = true;
+    return 0;
+}
+
+// ---- fp64 -> residue planes ---------------------------------------------------------------------------------------
+// src: rows x cols (row-major, ld); dst plane l: rows x ldd int8 at dst + l * plane_stride.  scale = 2^(52-e).
+// flag: set to 1 when an entry does not fit (|x| scale >= 2^53): the caller then refuses the emulated path.
+__global__ __launch_bounds__(256) void rns_convert_kernel(const double *src, long ld, long rows, long cols4, signed char *dst,
+                                                          long plane_stride, long ldd, double scale, int *flag) {
+    const long c4 = blockIdx.x * 256L + threadIdx.x;  // group of 4 consecutive columns
+    const long r = blockIdx.y;
+    if (c4 >= cols4) return;
+    const double *sp = src + r * ld + c4 * 4;
+    const double2_t a = *(const double2_t *)sp, b = *(const double2_t *)(sp + 2);
+    double v[4] = {rint(a[0] * scale), rint(a[1] * scale), rint(b[0] * scale), rint(b[1] * scale)};
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bad |= !(fabs(v[i]) < 0x1p53);
+    if (bad) atomicOr(flag, 1);
+#pragma unroll
+    for (int l = 0; l < RNS_T; ++l) {
+        const double p = c_rns.pd[l], ip = c_rns.inv_pd[l];
+        unsigned packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double q = rint(v[i] * ip);
+            double res = fma(-q, p, v[i]);  // exact: the true remainder is an integer of magnitude <= p
+            const int ri = (int)res;   // |ri| <= 127 (see h_moduli)
+            packed |= ((unsigned)ri & 0xffu) << (8 * i);
+        }
+        *(unsigned *)(dst + l * plane_stride + r * ldd + c4 * 4) = packed;
+    }
+}
+
+void launch_rns_convert(hipStream_t s, const double *src, long ld, long rows, long cols, signed char *dst,
+                        long plane_stride, long ldd, double scale, int *flag) {
+    const long cols4 = cols / 4;
+    dim3 grid((unsigned)((cols4 + 255) / 256), (unsigned)rows);
+    hipLaunchKernelGGL(rns_convert_kernel, grid, dim3(256), 0, s, src, ld, rows, cols4, dst, plane_stride, ldd, scale, flag);
+}
+
+__device__ __forceinline__ int mod_sym(int s, float p, float inv_p) {
+    const float f = (float)s;                 // |s| < 2^24: exact
+    const float q = rintf(f * inv_p);
+    return (int)fmaf(-q, p, f);               // exact remainder, |r| <= 127 (see h_moduli)
+}
+
+
+// ---- residue GEMM: R_l[ti, tc] = (R_l[ti, tc] + A_l[ti rows, 0:K] B_l[tc rows, 0:K]^T) mod p_l, 256 x 256 workgroup tiles ---
+// A first version on 128 x 128 tiles (register-staged, 2 or 4 workgroups per CU) ran at 1.3 Pop/s whatever the occupancy;
+// 256 x 256 tiles halve the bytes staged per op (256 op/B).  8 waves as 2 x 4, each 128 x 64 =
+// 4 x 2 MFMA tiles (128 accumulator registers); K stages of 64 bytes (one workgroup per CU: latency has to be covered by
+// the pipeline, not by occupancy).  R blocks are 64 KB per (plane, 256-row tile, 256-column tile), again in register order.
+struct RnsGemm256Args {
+    const signed char *A;  // plane l, row r: A + l * a_plane + r * lda   (K bytes, contiguous)
+    long lda, a_plane;
+    const signed char *B;  // already offset to the first contracted column; row c: B + l * b_plane + c * ldb
+    long ldb, b_plane;
+    signed char *R;        // block (l, ti, tc) at R + ((l * mt_all + ti) * nt_all + tc) * 65536
+    int mt_all, nt_all;
+    int mt, c0, c1;        // 256-row tiles 0..mt, 256-column tiles c0..c1
+    int K;                 // multiple of 128
+    int kpanel;            // an exact in-register reduction mod p is applied every kpanel bytes of K (<= 896)
+    int first;
+    int sr, sc;            // super-tile counts: 8 row tiles x 4 column tiles each
+};
+
+// LDS ring of four 32 KB stages (A 256 rows x 64 B, then B 256 rows x 64 B), filled by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, three stages in flight ~ 1.5 us of cover: with 8 x 4 super-tiles 19 % of the operand requests are
+// first touches that miss L2, and one barrier per stage makes every stage as slow as its slowest line).  LDS-DMA writes a
+// wave instruction's 64 x 16 B linearly, so rows cannot be padded; the 16-byte chunk c of row r is stored in slot
+// c ^ ((r >> 2) & 3) instead (the permutation is applied to the per-lane SOURCE address), which makes the fragment reads
+// (16 rows x one chunk per ds_read_b128 lane group) conflict-free.
+#define R256_STAGE 32768
+
+__device__ __forceinline__ void rns_glds16(const signed char *src, unsigned char *lds_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_uniform, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * R256_STAGE];
+    const long nwg = gridDim.x, bid = blockIdx.x;
+    const long wg = (bid & 7) * (nwg >> 3) + (bid >> 3);  // nwg is a multiple of 32
+    const int within = (int)(wg & 31);
+    const long st = wg >> 5;
+    const int nst = a.sr * a.sc;
+    const int l = (int)(st / nst);
+    const int sti = (int)(st % nst);
+    const int ti = (sti % a.sr) * 8 + (within & 7);
+    const int tc = a.c0 + (sti / a.sr) * 4 + (within >> 3);
+    if (ti >= a.mt || tc >= a.c1) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const float p = c_rns.p[l], inv_p = c_rns.inv_p[l];
+
+    const signed char *Ag = a.A + (long)l * a.a_plane + (long)ti * 256 * a.lda;
+    const signed char *Bg = a.B + (long)l * a.b_plane + (long)tc * 256 * a.ldb;
+    signed char *Rb = a.R + (((long)l * a.mt_all + ti) * a.nt_all + tc) * 65536 + (long)(wave * 8) * 1024 + lane * 16;
+
+    // the old residues of the whole tile first (8 x 16 B per lane): oldest in the memory queue, so the first counted
+    // wait of the K loop covers them and their HBM latency overlaps the prologue.  (Loaded tile by tile in the epilogue
+    // they cost 8 serialised round trips per workgroup: the stores in between keep the compiler from batching them.)
+    int4_t cold[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) cold[t] = int4_t{0, 0, 0, 0};
+    if (!a.first) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cold[t] = *(const int4_t *)(Rb + t * 1024);
+    }
+
+    // DMA map: wave w fills rows w*32 .. w*32+31 of A and of B with two instructions each (16 rows x 64 B per
+    // instruction); lane i -> row + (i >> 2), LDS slot i & 3, source chunk (i & 3) ^ ((row >> 2) & 3)
+    const int drow = wave * 32 + (lane >> 2);
+    const int dch0 = ((lane & 3) ^ ((drow >> 2) & 3)) * 16;           // rows drow and drow + 16 share (row >> 2) & 3 ...
+    const int dch1 = ((lane & 3) ^ (((drow + 16) >> 2) & 3)) * 16;    // ... only when bit 4 does not reach bits 2..3: it does not
+    const signed char *ga0 = Ag + (long)drow * a.lda + dch0;
+    const signed char *ga1 = Ag + (long)(drow + 16) * a.lda + dch1;
+    const signed char *gb0 = Bg + (long)drow * a.ldb + dch0;
+    const signed char *gb1 = Bg + (long)(drow + 16) * a.ldb + dch1;
+    unsigned char *la = smem + wave * 32 * 64;   // wave-uniform
+    const int nk = a.K / 64;
+    const int kred = a.kpanel / 64;
+
+    auto issue = [&](int kt) {
+        unsigned char *sb = la + (kt & 3) * R256_STAGE;
+        const long ko = (long)kt * 64;
+        rns_glds16(ga0 + ko, sb);
+        rns_glds16(ga1 + ko, sb + 1024);
+        rns_glds16(gb0 + ko, sb + 16384);
+        rns_glds16(gb1 + ko, sb + 16384 + 1024);
+    };
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+
+    int16v_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
+
+    // fragment reads: row (lane & 31) of the MFMA tile, logical chunk 2 ks + (lane >> 5), slot = chunk ^ ((row >> 2) & 3)
+    const int frow = lane & 31, fh = lane >> 5;
+    int aoffs[4][2], boffs[2][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int r = wm * 128 + m * 32 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) aoffs[m][ks] = r * 64 + (((2 * ks + fh) ^ ((r >> 2) & 3)) * 16);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int r = wn * 64 + n * 32 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) boffs[n][ks] = 16384 + r * 64 + (((2 * ks + fh) ^ ((r >> 2) & 3)) * 16);
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's DMA of stage kt has landed once at most the two younger stages' are outstanding
+        const int younger = nk - 1 - kt;
+        if (younger >= 2)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // ... and every other wave's; all waves are also done reading stage kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char *sb = smem + (kt & 3) * R256_STAGE;
+        // fragments of both k steps are requested before the first MFMA; the DMA of stage kt+3 (into the buffer of stage
+        // kt-1) is issued between the two groups of reads, behind the LDS latency of the first
+        int4_t af[2][4], bf[2][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[0][m] = *(const int4_t *)(sb + aoffs[m][0]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[0][n] = *(const int4_t *)(sb + boffs[n][0]);
+        if (kt + 3 < nk) issue(kt + 3);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[1][m] = *(const int4_t *)(sb + aoffs[m][1]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[1][n] = *(const int4_t *)(sb + boffs[n][1]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][m], bf[ks][n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if ((kt + 1) % kred == 0 && kt + 1 < nk) {   // panel boundary inside one launch: keep the sums below 2^24
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = mod_sym(acc[m][n][r], p, inv_p);
+        }
+    }
+
+    // epilogue: (old + sum) mod p, 16 bytes per lane per MFMA tile
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int t = m * 2 + n;
+            int4_t out;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned packed = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int s = acc[m][n][w * 4 + b] + (int)(signed char)((unsigned)cold[t][w] >> (8 * b));
+                    packed |= ((unsigned)mod_sym(s, p, inv_p) & 0xffu) << (8 * b);
+                }
+                out[w] = (int)packed;
+            }
+            *(int4_t *)(Rb + t * 1024) = out;
+        }
+}
+
+void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
+                        long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int kpanel,
+                        int first) {
+    if (mt <= 0 || c1 <= c0 || K <= 0) return;
+    RnsGemm256Args a;
+    a.A = A; a.lda = lda; a.a_plane = a_plane; a.B = B; a.ldb = ldb; a.b_plane = b_plane; a.R = R;
+    a.mt_all = mt_all; a.nt_all = nt_all; a.mt = mt; a.c0 = c0; a.c1 = c1; a.K = K; a.kpanel = kpanel; a.first = first;
+    a.sr = (mt + 7) / 8;
+    a.sc = (c1 - c0 + 3) / 4;
+    const long nwg = (long)RNS_T * a.sr * a.sc * 32;
+    hipLaunchKernelGGL(rns_gemm256_kernel, dim3((unsigned)nwg), dim3(512), 0, s, a);
+}
+
+// reconstruction from the 64 KB blocks: one workgroup (512 threads, the GEMM's thread layout) per (256-row tile,
+// 256-column tile); only the 128-column tiles c0_128 .. c1_128 are touched, rows below `rows` only
+__global__ __launch_bounds__(512) void rns_reconstruct256_kernel(const signed char *R, int mt_all, int nt_all, int tc0, int ntc,
+                                                                 int c0_128, int c1_128, long rows, double *T, long ldt,
+                                                                 double out_scale) {
+    const int blk = blockIdx.x >> 3;   // eight workgroups per 64 KB block: one MFMA tile of each wave's eight per workgroup
+    const int ti = blk / ntc, tc = tc0 + blk % ntc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int col128 = (tc * 256 + wn * 64) >> 7;
+    if (col128 < c0_128 || col128 >= c1_128) return;   // wave-uniform
+    const long plane = (long)mt_all * nt_all * 65536;
+    const signed char *Rb = R + ((long)ti * nt_all + tc) * 65536 + (long)(wave * 8) * 1024 + lane * 16;
+    const double MAGIC = 0x1.8p8;  // 1.5 * 2^(52-44): rounds to multiples of 2^-44
+    {
+        const int t = blockIdx.x & 7;
+        const int m = t >> 1, n = t & 1;
+        const long row0 = (long)ti * 256 + wm * 128 + m * 32 + 4 * (lane >> 5);
+        if ((long)ti * 256 + wm * 128 + m * 32 >= rows) return;   // wave-uniform
+        // everything this tile needs is requested before any of it is used: the 16 residue vectors and the 16 fp64
+        // values of T to be updated (one batch of loads instead of 32 dependent round trips)
+        int4_t v[RNS_T];
+#pragma unroll
+        for (int l = 0; l < RNS_T; ++l) v[l] = *(const int4_t *)(Rb + l * plane + t * 1024);
+        const long col = (long)tc * 256 + wn * 64 + n * 32 + (lane & 31);
+        double told[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = row0 + (r & 3) + 8 * (r >> 2);
+            told[r] = row < rows ? T[row * ldt + col] : 0.0;
+        }
+        double H[16], L[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H[r] = L[r] = 0.0;
+#pragma unroll
+        for (int l = 0; l < RNS_T; ++l) {
+            const float p = c_rns.p[l], inv_p = c_rns.inv_p[l];
+            const int q = c_rns.q[l];
+            const double ih = c_rns.ih[l], il = c_rns.il[l];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int res = (int)(signed char)((unsigned)v[l][r >> 2] >> (8 * (r & 3)));
+                const float wf0 = (float)(res * q);                 // |r q| < 2^15
+                const float k = rintf(wf0 * inv_p);
+                const double w = (double)fmaf(-k, p, wf0);          // representative of r q mod p, |w| <= p
+                const double t1 = w * ih;
+                const double hi = (t1 + MAGIC) - MAGIC;
+                double lo = fma(w, ih, -hi);
+                lo = fma(w, il, lo);
+                H[r] += hi;
+                L[r] += lo;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double f = (H[r] - rint(H[r])) + L[r];
+            f -= rint(f);
+            const long row = row0 + (r & 3) + 8 * (r >> 2);
+            if (row < rows) T[row * ldt + col] = told[r] - f * out_scale;
+        }
+    }
+}
+
+void launch_rns_reconstruct256(hipStream_t s, const signed char *R, int mt_all, int nt_all, int mt, int c0_128, int c1_128,
+                               long rows, double *T, long ldt, double scale_2e) {
+    if (mt <= 0 || c1_128 <= c0_128) return;
+    long double Pl = 1.0L;
+    for (int l = 0; l < RNS_T; ++l) Pl *= (long double)h_moduli[l];
+    const double P_scaled = (double)(Pl * 0x1p-104L);
+    const int tc0 = c0_128 / 2, tc1 = (c1_128 + 1) / 2;
+    hipLaunchKernelGGL(rns_reconstruct256_kernel, dim3((unsigned)(8 * mt * (tc1 - tc0))), dim3(512), 0, s, R, mt_all, nt_all, tc0,
+                       tc1 - tc0, c0_128, c1_128, rows, T, ldt, P_scaled * scale_2e);
+}

@@ -1,0 +1,123 @@
+"""GPU: the fp64-emulation prototype (option "emulate_fp64", default OFF): the candidate solve's updates run as int8
+MFMA contractions in residue form (csrc/rns.hip).  It only counts if it meets the north-star tolerances wherever the
+true-fp64 path does: golden vectors, the extended-precision truth of the stress cases, ragged shapes, and the headline
+configuration against the independent full-size oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import Case, relmax
+from gaussian_process_optimization_amd import _lib
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def h():
+    hd = _lib.Handle(0)
+    yield hd
+    hd.close()
+
+
+def _tags():
+    g = np.load(os.path.join(HERE, "golden", "gp_golden.npz"))
+    return sorted({k.split("/")[0] for k in g.files if k.startswith("N512") or k.startswith("N300")})
+
+
+@pytest.mark.parametrize("tag", _tags())
+def test_emulated_candidate_solve_on_golden_cases(golden, h, tag):
+    c = Case(golden, tag)
+    noise = float(c.noise)
+    h.set_option("panel_tiles", 1)     # N <= 512: four one-tile panels, so three residue updates per candidate tile
+    h.set_option("emulate_fp64", 1)
+    try:
+        h.set_data(c.X, c.Y)
+        h.set_params(int(c.kernel), int(c.ard), float(c.variance), c.lengthscale, noise)
+        h.fit()
+        h.set_candidates(c.Xs)
+        mu, var = h.predict(True)
+        _, var0 = h.predict(False)
+        if noise >= 1e-4:
+            assert relmax(mu, c.mu) < 1e-6
+            assert np.max(np.abs(var - c.var) / np.abs(c.var)) < 1e-6
+            assert np.max(np.abs(var0 - c.var_noiseless)) < 1e-6 * float(c.variance)
+            a = h.acq(_lib.GP_ACQ_EI, 0.01, float(c.fmin))
+            assert np.max(np.abs(a - c.neg_EI)) <= 1e-6 * np.max(np.abs(c.neg_EI))
+        else:   # stress: against the extended-precision truth, like the fp64 path (test_gpu_parity.py)
+            T = np.load(os.path.join(HERE, "golden", "gp_truth.npz"))
+            t = Case(T, tag)
+            for hip, ref, truth, scale in ((mu, c.mu, t.mu, float(np.max(np.abs(t.mu)))),
+                                           (var / t.var, c.var / t.var, t.var / t.var, 1.0),
+                                           (var0, c.var_noiseless, t.var_noiseless, float(c.variance))):
+                e_hip = float(np.max(np.abs(hip - truth))) / scale
+                e_ref = float(np.max(np.abs(ref - truth))) / scale
+                assert e_hip <= max(1e-6, 4 * e_ref), (e_hip, e_ref)
+        # against the true-fp64 device path: the residue arithmetic is exact, only the operands are rounded to
+        # fixed point (one ulp of the largest entry)
+        h.set_option("emulate_fp64", 0)
+        mu2, var2 = h.predict(True)
+        assert np.max(np.abs(mu - mu2)) <= (1e-9 if noise >= 1e-4 else 1e-6) * max(1.0, np.max(np.abs(mu2)))
+        assert np.max(np.abs(var - var2)) <= (1e-9 if noise >= 1e-4 else 1e-6) * float(c.variance)
+    finally:
+        h.set_option("emulate_fp64", 0)
+        h.set_option("panel_tiles", 6)
+
+
+@pytest.mark.parametrize("N,D,M,pt,variance", [(1500, 3, 700, 2, 1.7), (2048, 5, 300, 4, 0.3), (1100, 2, 129, 3, 40.0),
+                                               (900, 4, 1, 1, 1.0), (3000, 8, 1000, 6, 1.0), (2500, 6, 333, 7, 2.5)])
+def test_emulated_equals_fp64_path_on_ragged_shapes(h, N, D, M, pt, variance):
+    X, Y, Xs = O.synthetic_problem(N, D, M, seed=N + D)
+    h.set_option("panel_tiles", pt)
+    try:
+        h.set_data(X, Y)
+        h.set_params(1, 0, variance, [0.7], 1e-2)
+        h.fit()
+        h.set_candidates(Xs)
+        m0, v0 = h.predict(True)
+        h.set_option("emulate_fp64", 1)
+        m1, v1 = h.predict(True)
+        assert np.max(np.abs(m1 - m0)) <= 1e-10 * max(1.0, np.max(np.abs(m0)))
+        assert np.max(np.abs(v1 - v0)) <= 1e-10 * variance
+        gp = O.OracleGP(X, Y, O.Matern52(D, variance, 0.7), 1e-2)
+        mo, vo = gp.predict(Xs)
+        assert relmax(m1, mo) < 1e-6 and np.max(np.abs(v1 - vo) / vo) < 1e-6
+        # the one-call entry point falls back to fit + emulated predict
+        f1, m2, v2 = h.fit_predict(True)
+        assert np.array_equal(m2, m1) and np.array_equal(v2, v1)
+        h.set_option("panel_tiles", 8)
+        h.fit()
+        with pytest.raises(ValueError):
+            h.predict(True)
+    finally:
+        h.set_option("emulate_fp64", 0)
+        h.set_option("panel_tiles", 6)
+
+
+def test_emulated_headline_configuration_full_size(h):
+    """C3 (N=16384, D=8, M=10^4) with the emulated candidate solve: mean / variance of 64 candidates against the
+    independent full-size oracle at 1e-6, and all 10^4 against the true-fp64 device path."""
+    from test_gpu_fullsize import _oracle_full_size
+    N, D, M = 16384, 8, 10000
+    X, Y, Xs = O.synthetic_problem(N, D, M, seed=1234)
+    ls = O.default_lengthscale(D, False)
+    h.set_data(X, Y)
+    h.set_params(0, 0, 1.0, ls, 1e-2)
+    h.fit()
+    h.set_candidates(Xs)
+    m0, v0 = h.predict(True)
+    h.set_option("emulate_fp64", 1)
+    try:
+        m1, v1 = h.predict(True)
+        ph = {p["name"]: p["ms"] for p in h.phases()}
+    finally:
+        h.set_option("emulate_fp64", 0)
+    assert np.max(np.abs(m1 - m0)) <= 1e-9 * np.max(np.abs(m0))
+    assert np.max(np.abs(v1 - v0) / v0) <= 1e-9
+    pick = np.unique(np.r_[np.linspace(0, M - 1, 62).astype(int), int(np.argmax(v1)), int(np.argmin(v1))])
+    lml0, _, alpha0, mu_o, var_o = _oracle_full_size(O.RBF(D, 1.0, ls), X, Y, 1e-2, Xs[pick])
+    assert np.max(np.abs(m1[pick] - mu_o)) <= 1e-6 * np.max(np.abs(mu_o))
+    assert np.max(np.abs(v1[pick] - var_o) / var_o) <= 1e-6
+    print("emulated candidate solve phases (ms):", ph)

@@ -149,6 +149,11 @@ struct gp_ctx {
     double *dComm = nullptr;  // gather scratch of the top-k exchange
     long capComm = 0;
     // fp64 emulation on the int8 matrix cores (rns.hip), candidate solve only
+    // cooperative tail of the factorisation (potrf.hip: chol_tail_kernel)
+    int tail_tiles = 0;      // trailing tile columns handed to ONE persistent launch (0 = off)
+    int tail_wgs = 0;        // its workgroup count (0 = automatic)
+    int ncu = 0;
+    unsigned *dSync = nullptr;
     int emulate_fp64 = 0;
     int rns_pair = 1;  // two panels per residue launch
     signed char *dLr = nullptr, *dSr = nullptr, *dRr = nullptr;  // residue planes of L, of the current S panel, accumulator
@@ -413,12 +418,18 @@ int gp_create(gp_t **out, int device) {
         g->s_inv = d.inv;
         g->s_pred = d.pred;
     }
+    {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, device) == hipSuccess) g->ncu = pr.multiProcessorCount;
+    }
     hipError_t e = hipMalloc((void **)&g->dInfo, sizeof(int) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->dSync, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&g->dScal, sizeof(double) * 512);
     if (e == hipSuccess) e = hipMalloc((void **)&g->dRedV, sizeof(double) * 512);
     if (e == hipSuccess) e = hipMalloc((void **)&g->dRedI, sizeof(long long) * 1024);
     if (e != hipSuccess) {
         if (g->dInfo) hipFree(g->dInfo);
+        if (g->dSync) hipFree(g->dSync);
         for (double *p : {g->dScal, g->dRedV})
             if (p) hipFree(p);
         if (g->dRedI) hipFree(g->dRedI);
@@ -471,6 +482,7 @@ int gp_destroy(gp_t *g) {
     for (double *p : ptrs)
         if (p) hipFree(p);
     if (g->dInfo) hipFree(g->dInfo);
+    if (g->dSync) hipFree(g->dSync);
     if (g->dRedI) hipFree(g->dRedI);
     for (signed char *p : {g->dLr, g->dSr, g->dRr})
         if (p) hipFree(p);
@@ -541,6 +553,12 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->trsm_rows64 = (int)value;
     } else if (!strcmp(name, "trsm_waves8")) {
         g->trsm_waves8 = (int)value;
+    } else if (!strcmp(name, "tail_tiles")) {
+        if (value < 0 || value > 4096) return fail(GP_ERR_ARG, "tail_tiles out of range");
+        g->tail_tiles = (int)value;
+    } else if (!strcmp(name, "tail_wgs")) {
+        if (value < 0 || value > 1024) return fail(GP_ERR_ARG, "tail_wgs out of range");
+        g->tail_wgs = (int)value;
     } else if (!strcmp(name, "rns_pair")) {
         g->rns_pair = value ? 1 : 0;
     } else if (!strcmp(name, "emulate_fp64")) {
@@ -656,11 +674,23 @@ int gp_set_params(gp_t *g, int kernel, int ard, double variance, const double *l
 }
 
 // ---- blocked right-looking Cholesky (two-level: 128-column steps inside panel_tiles-wide panels) ----
+// Workgroups of the cooperative tail: enough to spread a column's rank-128 update, never more than the CUs (every
+// workgroup has to be resident: the kernel synchronises through grid barriers)
+static int tail_workgroups(gp_ctx *g, int t0, int R1) {
+    if (g->tail_wgs > 0) return std::min(g->tail_wgs, std::max(1, g->ncu));
+    const long tiles = (long)(R1 - t0) * (R1 - t0) / 4;
+    return (int)std::max<long>(1, std::min<long>(tiles, std::max(1, g->ncu)));
+}
+
 // A: nt x nt tiles (lower) plus R1 - nt extra row tiles that ride through the panel solves and updates (the RHS rows)
 static void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, int *info) {
     const int W = g->panel_tiles;
     hipStream_t s = g->s;
     for (int J0 = 0; J0 < nt; J0 += W) {
+        if (g->tail_tiles > 0 && nt - J0 <= g->tail_tiles) {   // the rest in one persistent launch
+            launch_chol_tail(s, A, lda, invL, info, J0, nt, R1, g->dSync, tail_workgroups(g, J0, R1));
+            return;
+        }
         const int J1 = std::min(J0 + W, nt);
         for (int j = J0; j < J1; ++j) {
             launch_potrf_tile(s, A, lda, j, invL, info);
@@ -756,6 +786,13 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     const int nJ = (int)pb.size() - 2;
     for (int J = 0; J < nJ; ++J) {
         const int J0 = pb[J], J1 = pb[J + 1], J2 = pb[J + 2];
+        if (!pp.on && g->tail_tiles > 0 && nt - J0 <= g->tail_tiles) {
+            // the trailing columns J0 .. nt-1 in one persistent launch on the chain stream: panel J's columns are
+            // complete in stream order (look-ahead update J-1), everything right of them once bulk(J-1) is
+            if (J >= 1 && J0 < nt) hipStreamWaitEvent(sp, la_event(g, EV_BULK, J - 1), 0);
+            launch_chol_tail(sp, A, lda, g->dInvL, g->dInfo, J0, nt, R1, g->dSync, tail_workgroups(g, J0, R1));
+            break;
+        }
         // in-panel updates: left-looking while the panel is tall (column j receives columns J0..j-1 in ONE
         // contraction of K = 128 (j-J0): a third of the C traffic of j-J0 rank-128 updates and a longer K, which is
         // what counts while the chain shares the chip with the trailing update), right-looking once the panel is
@@ -1156,7 +1193,11 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         }
         phase_end(g, ph);
         HIPCHK(hipMemcpyAsync(&info, g->dInfo, sizeof(int), hipMemcpyDeviceToHost, g->s));
+        unsigned sync_words[2] = {0, 0};
+        if (g->tail_tiles > 0) HIPCHK(hipMemcpyAsync(sync_words, g->dSync, sizeof sync_words, hipMemcpyDeviceToHost, g->s));
         HIPCHK(hipStreamSynchronize(g->s));
+        if (sync_words[1] != 0)
+            return fail(GP_ERR_HIP, "cooperative tail kernel: grid barrier timed out (a workgroup was not resident)");
         if (info == 0) break;
         // jitter ladder, GPy/GPy/util/linalg.py:62-75
         if (!(diag0 > 0.0)) return fail(GP_ERR_NOT_PD_DIAG, "not pd: non-positive diagonal elements");
@@ -2129,7 +2170,11 @@ int gp_posterior_samples(gp_t *g, int include_noise, const double *Z, int S, int
         HIPCHK(hipMemsetAsync(g->dInfo, 0, sizeof(int) * 4, g->s));
         factor_buf(g, C, Mpad, mt, mt, invL, g->dInfo);
         HIPCHK(hipMemcpyAsync(&info, g->dInfo, sizeof(int), hipMemcpyDeviceToHost, g->s));
+        unsigned sync_words[2] = {0, 0};
+        if (g->tail_tiles > 0) HIPCHK(hipMemcpyAsync(sync_words, g->dSync, sizeof sync_words, hipMemcpyDeviceToHost, g->s));
         HIPCHK(hipStreamSynchronize(g->s));
+        if (sync_words[1] != 0)
+            return fail(GP_ERR_HIP, "cooperative tail kernel: grid barrier timed out (a workgroup was not resident)");
         if (info == 0) break;
         // jitchol: mean(diag) * 1e-6 * 10^k (linalg.py:62-75); the posterior covariance's diagonal is bounded by diag0
         if (!(diag0 > 0.0)) return fail(GP_ERR_NOT_PD_DIAG, "not pd: non-positive diagonal elements");

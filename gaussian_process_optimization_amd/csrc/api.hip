@@ -157,9 +157,13 @@ struct gp_ctx {
     int emulate_fp64 = 0;
     int rns_pair = 1;  // two panels per residue launch
     signed char *dLr = nullptr, *dSr = nullptr, *dRr = nullptr;  // residue planes of L, of the current S panel, accumulator
-    long capLr = 0, capSr = 0, capRr = 0;
-    bool lr_valid = false;
-    int lr_W = 0;
+    signed char *dRm = nullptr;                                   // residue accumulator of the trailing matrix (factorisation)
+    long capLr = 0, capSr = 0, capRr = 0, capRm = 0;
+    bool lr_valid = false;          // dLr belongs to the current factor
+    std::vector<char> lr_done;      // ... per panel: rows below the panel's diagonal block converted
+    int lr_W = 0, lr_e = 0;
+    double jitter_try = 0.0;        // jitter of the factorisation attempt in progress (fixes the fixed-point scale)
+    int emulate_fit = 1;            // emulate_fp64 also covers the factorisation's trailing update
     bool dead = false;  // gp_shutdown ran: the device's streams are gone, only gp_destroy is still valid
 };
 
@@ -484,7 +488,7 @@ int gp_destroy(gp_t *g) {
     if (g->dInfo) hipFree(g->dInfo);
     if (g->dSync) hipFree(g->dSync);
     if (g->dRedI) hipFree(g->dRedI);
-    for (signed char *p : {g->dLr, g->dSr, g->dRr})
+    for (signed char *p : {g->dLr, g->dSr, g->dRr, g->dRm})
         if (p) hipFree(p);
     for (auto &kv : g->tile_lists) hipFree(kv.second);
     // events recorded on the shared streams go first; the streams themselves belong to the per-device set shared by
@@ -561,6 +565,8 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->tail_wgs = (int)value;
     } else if (!strcmp(name, "rns_pair")) {
         g->rns_pair = value ? 1 : 0;
+    } else if (!strcmp(name, "emulate_fit")) {
+        g->emulate_fit = value ? 1 : 0;
     } else if (!strcmp(name, "emulate_fp64")) {
         g->emulate_fp64 = value ? 1 : 0;
         g->predicted = false;
@@ -746,6 +752,78 @@ static void build_panel_inv_one(gp_ctx *g, hipStream_t s, int J, int W, int nt) 
     launch_transpose_blocks(s, g->dInvP + (long)J * PB * PB, Wb, PB, 1);
 }
 
+static int byte_realloc(signed char **p, long *cap, long need) {
+    if (need <= *cap && *p) return 0;
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void **)p, (size_t)need);
+    if (e != hipSuccess) return fail(GP_ERR_HIP, "hipMalloc(%ld bytes) -> %s", need, hipGetErrorString(e));
+    *cap = need;
+    return 0;
+}
+
+// The candidate solve S = T L^-T with the running right-hand side's updates  T[:, > J] -= S_J L[> J, J]^T  carried in
+// residue form on the int8 matrix cores (rns.hip; option "emulate_fp64").  Per panel J: the fp64 columns of T are
+// rebuilt from the exact integer accumulator, S_J = T_J invP_J^T runs in fp64 as before (5 % of the flops), S_J is
+// converted to residues and ONE int8 launch (16 moduli) applies it to every column to the right.
+// Shared state of the residue paths: fixed-point scale, residue planes of L (zeroed padding), per-panel conversion.
+struct RnsGeom {
+    int e = 0;
+    double scale = 1.0, back = 1.0;
+    long Lrows = 0, Lplane = 0;
+    int nt256 = 0;
+};
+
+static int rns_prepare(gp_ctx *g, double jitter, RnsGeom *r) {
+    const long Npad = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    const int W = std::min(g->panel_tiles, nt);
+    if ((long)W * GP_TILE > 896) return fail(GP_ERR_ARG, "emulate_fp64 needs panel_tiles <= 7 (int32 sums must stay below 2^24)");
+    if (g->N > (1L << 20)) return fail(GP_ERR_ARG, "emulate_fp64 needs N <= 2^20");
+    if (rns_init_constants(g->device)) return fail(GP_ERR_HIP, "rns constants");
+    r->Lrows = round_up(Npad, 256);
+    r->Lplane = r->Lrows * Npad;
+    r->nt256 = (int)(r->Lrows / 256);
+    // common power-of-two scale: |L_ij| <= sqrt(max diag of Ky), |S_ik| <= sqrt(prior variance); one spare bit
+    const double diag0 = (g->kp.gower ? std::pow(g->kp.variance, g->D) : g->kp.variance) + g->noise + 1e-8 + jitter;
+    int e = 1 + (int)std::ceil(std::log2(std::sqrt(std::max(diag0, 1e-300))));
+    if (e < 0) e = 0;
+    r->e = e;
+    r->scale = std::ldexp(1.0, 52 - e);
+    r->back = std::ldexp(1.0, 2 * e);
+    const long need = (long)GP_RNS_T * r->Lplane;
+    if (need > g->capLr || !g->dLr) {
+        int rc = byte_realloc(&g->dLr, &g->capLr, need);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(g->dLr, 0, (size_t)need, g->s));
+        HIPCHK(hipStreamSynchronize(g->s));
+        g->lr_valid = false;
+    }
+    const int nJ = (nt + W - 1) / W;
+    if (!g->lr_valid || g->lr_W != W || g->lr_e != e || (int)g->lr_done.size() != nJ) {
+        g->lr_done.assign(nJ, 0);
+        g->lr_W = W;
+        g->lr_e = e;
+        g->lr_valid = true;
+    }
+    return 0;
+}
+
+// residues of L's panel J (rows strictly below its diagonal block), once per factor
+static void rns_convert_panel(gp_ctx *g, hipStream_t s, const RnsGeom &r, int J, int *flag) {
+    const long Npad = g->Npad, lda = g->Npad;
+    const int nt = (int)(Npad / GP_TILE), W = g->lr_W;
+    const int J0 = J * W, J1 = std::min(J0 + W, nt);
+    if (J1 >= nt || g->lr_done[J]) return;
+    launch_rns_convert(s, g->dA + (long)J1 * GP_TILE * lda + (long)J0 * GP_TILE, lda, Npad - (long)J1 * GP_TILE,
+                       (long)(J1 - J0) * GP_TILE, g->dLr + (long)J1 * GP_TILE * Npad + (long)J0 * GP_TILE, r.Lplane, Npad,
+                       r.scale, flag);
+    g->lr_done[J] = 1;
+}
+
+static inline long Npad_rows(gp_ctx *g) { return g->Npad; }
+
 static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     int rc;
     if ((rc = ensure_bulk_stream(g))) return rc;
@@ -784,6 +862,20 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     pb.push_back(nt);
     pb.push_back(nt);
     const int nJ = (int)pb.size() - 2;
+    // "emulate_fp64": the trailing update (the launches of the bulk stream) in residue form on the int8 matrix cores
+    // (rns.hip).  The Schur complement right of the look-ahead panel lives as Ky (untouched, in dA) minus an exact integer
+    // accumulator dRm; a panel's columns are rebuilt in fp64 once, right before they become the look-ahead target.  The
+    // chain (diagonal tiles, panel solves, in-panel and look-ahead updates) and the right-hand-side tile row stay fp64.
+    const bool emu = g->emulate_fp64 && g->emulate_fit && !pp.on && (PB % 256 == 0) && PB <= 896 &&
+                     !(g->panel_tiles_tail > 0) && !(g->tail_tiles > 0);
+    RnsGeom rg;
+    int *rflag = g->dInfo + 2;
+    if (emu) {
+        if ((rc = rns_prepare(g, g->jitter_try, &rg))) return rc;
+        const long need = (long)GP_RNS_T * rg.nt256 * rg.nt256 * 65536;
+        if ((rc = byte_realloc(&g->dRm, &g->capRm, need))) return rc;
+        HIPCHK(hipMemsetAsync(rflag, 0, sizeof(int), g->s));
+    }
     for (int J = 0; J < nJ; ++J) {
         const int J0 = pb[J], J1 = pb[J + 1], J2 = pb[J + 2];
         if (!pp.on && g->tail_tiles > 0 && nt - J0 <= g->tail_tiles) {
@@ -846,12 +938,25 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
         // the look-ahead update is on the critical path: enqueue it before the trailing update so that its
         // workgroups reach the dispatcher first once bulk(J-1) has drained
         if (J >= 1) hipStreamWaitEvent(sp, la_event(g, EV_BULK, J - 1), 0);
+        // emulated: the look-ahead panel's columns take everything the residue accumulator holds for them (panels
+        // 0 .. J-1) before the fp64 update with panel J
+        if (emu && J >= 1)
+            launch_rns_reconstruct256(sp, g->dRm, rg.nt256, rg.nt256, rg.nt256, J1, J2, Npad_rows(g), A, lda, rg.back, 1);
         gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
              TileSet{0, R1, J1, J2, 1});
         if (J2 < nt) {
             hipStreamWaitEvent(sb, eF, 0);
-            gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
-                 TileSet{0, R1, J2, nt, 1});
+            if (emu) {
+                rns_convert_panel(g, sb, rg, J, rflag);
+                launch_rns_gemm256(sb, g->dLr + (long)J0 * GP_TILE, g->Npad, rg.Lplane, g->dLr + (long)J0 * GP_TILE, g->Npad,
+                                   rg.Lplane, g->dRm, rg.nt256, rg.nt256, rg.nt256, J2 / 2, rg.nt256, K, K, J == 0 ? 1 : 0, 1);
+                // the right-hand-side tile row rides in fp64
+                gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
+                     TileSet{nt, R1, J2, nt, 0});
+            } else {
+                gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
+                     TileSet{0, R1, J2, nt, 1});
+            }
             hipEventRecord(la_event(g, EV_BULK, J), sb);
         }
     }
@@ -976,65 +1081,36 @@ static void solve_rows(gp_ctx *g, double *T, double *S, int mt, int trapezoid, i
     }
 }
 
-static int byte_realloc(signed char **p, long *cap, long need) {
-    if (need <= *cap && *p) return 0;
-    if (*p) hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    hipError_t e = hipMalloc((void **)p, (size_t)need);
-    if (e != hipSuccess) return fail(GP_ERR_HIP, "hipMalloc(%ld bytes) -> %s", need, hipGetErrorString(e));
-    *cap = need;
-    return 0;
-}
-
-// The candidate solve S = T L^-T with the running right-hand side's updates  T[:, > J] -= S_J L[> J, J]^T  carried in
-// residue form on the int8 matrix cores (rns.hip; option "emulate_fp64").  Per panel J: the fp64 columns of T are
-// rebuilt from the exact integer accumulator, S_J = T_J invP_J^T runs in fp64 as before (5 % of the flops), S_J is
-// converted to residues and ONE int8 launch (16 moduli) applies it to every column to the right.
 static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
-    const long Npad = g->Npad, lda = g->Npad;
+    const long Npad = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
     const int W = g->invp_W;
     const long PB = (long)W * GP_TILE, Mcpad = (long)mt * GP_TILE;
-    if (PB > 896) return fail(GP_ERR_ARG, "emulate_fp64 needs panel_tiles <= 7 (int32 sums must stay below 2^24)");
-    if (g->N > (1L << 20)) return fail(GP_ERR_ARG, "emulate_fp64 needs N <= 2^20");
     int rc;
-    if (rns_init_constants(g->device)) return fail(GP_ERR_HIP, "rns constants");
+    RnsGeom r;
+    if (W != std::min(g->panel_tiles, nt)) return fail(GP_ERR_STATE, "emulate_fp64: panel width changed since the fit");
+    if ((rc = rns_prepare(g, g->jitter, &r))) return rc;
     // 256 x 256 workgroup tiles: rows / columns padded to multiples of 256 (zero residues in the padding)
-    const long Mc256 = round_up(Mcpad, 256), Lrows = round_up(Npad, 256);
-    const int mt256 = (int)(Mc256 / 256), nt256 = (int)(Lrows / 256);
+    const long Mc256 = round_up(Mcpad, 256), Lrows = r.Lrows;
+    const int mt256 = (int)(Mc256 / 256), nt256 = r.nt256;
     const long KS = 2 * PB;   // up to two panels of S side by side (one launch then contracts both)
     auto zalloc = [&](signed char **p, long *cap, long need) -> int {
         if (need <= *cap && *p) return 0;
-        int r = byte_realloc(p, cap, need);
-        if (r) return r;
+        int r2 = byte_realloc(p, cap, need);
+        if (r2) return r2;
         if (hipMemsetAsync(*p, 0, (size_t)need, g->s) != hipSuccess) return fail(GP_ERR_HIP, "hipMemsetAsync");
-        g->lr_valid = false;
         return 0;
     };
-    if ((rc = zalloc(&g->dLr, &g->capLr, (long)GP_RNS_T * Lrows * Npad))) return rc;
+    (void)Lrows;
     if ((rc = zalloc(&g->dSr, &g->capSr, (long)GP_RNS_T * Mc256 * KS))) return rc;
     if ((rc = zalloc(&g->dRr, &g->capRr, (long)GP_RNS_T * mt256 * nt256 * 65536))) return rc;
     hipStream_t s = g->s;
     int *flag = g->dInfo + 2;
     HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), s));
-    // common power-of-two scale: |L_ij| <= sqrt(max diag of Ky), |S_ik| <= sqrt(prior variance); one spare bit
-    const double diag0 = (g->kp.gower ? std::pow(g->kp.variance, g->D) : g->kp.variance) + g->noise + 1e-8 + g->jitter;
-    int e = 1 + (int)std::ceil(std::log2(std::sqrt(std::max(diag0, 1e-300))));
-    if (e < 0) e = 0;
-    const double scale = std::ldexp(1.0, 52 - e), back = std::ldexp(1.0, 2 * e);
-    const long Lplane = Lrows * Npad, Splane = Mc256 * KS;
-    if (!g->lr_valid || g->lr_W != W) {   // residues of L, panel by panel (rows strictly below each diagonal panel block)
-        for (int J0 = 0; J0 < nt; J0 += W) {
-            const int J1 = std::min(J0 + W, nt);
-            if (J1 >= nt) break;
-            launch_rns_convert(s, g->dA + (long)J1 * GP_TILE * lda + (long)J0 * GP_TILE, lda, Npad - (long)J1 * GP_TILE,
-                               (long)(J1 - J0) * GP_TILE, g->dLr + (long)J1 * GP_TILE * Npad + (long)J0 * GP_TILE, Lplane,
-                               Npad, scale, flag);
-        }
-        g->lr_valid = true;
-        g->lr_W = W;
-    }
+    const int e = r.e;
+    const double scale = r.scale, back = r.back;
+    const long Lplane = r.Lplane, Splane = Mc256 * KS;
+    for (int J = 0; J < (int)g->lr_done.size(); ++J) rns_convert_panel(g, s, r, J, flag);
     // Panels are taken in pairs (J, J+1): panel J+1's columns receive panel J's update as a small launch of their own,
     // then ONE launch contracts both panels (K = 2 PB, an exact reduction mod p between the halves) into every column
     // further right -- half the round trips of the residue accumulator through HBM.
@@ -1163,6 +1239,8 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     int tries = 0;  // number of jittered attempts so far
     int info = 0;
     for (;;) {
+        g->lr_valid = false;     // residue planes of L belong to one factorisation attempt
+        g->jitter_try = jitter;
         int ph = phase_begin(g, "kbuild", 0.0, 8.0 * N * g->D + 8.0 * (double)N * N / 2);
         launch_kbuild(g->s, g->dA, lda, g->dX, N, Npad, g->kp, diag_add, 0);
         // jitchol retries factor (Ky + jitter I): the jitter lands on the assembled diagonal (linalg.py:69)
@@ -1198,6 +1276,11 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         HIPCHK(hipStreamSynchronize(g->s));
         if (sync_words[1] != 0)
             return fail(GP_ERR_HIP, "cooperative tail kernel: grid barrier timed out (a workgroup was not resident)");
+        if (g->emulate_fp64 && info == 0) {
+            int bad = 0;
+            HIPCHK(hipMemcpy(&bad, g->dInfo + 2, sizeof(int), hipMemcpyDeviceToHost));
+            if (bad) return fail(GP_ERR_STATE, "emulate_fp64: an entry of L left the fixed-point range");
+        }
         if (info == 0) break;
         // jitter ladder, GPy/GPy/util/linalg.py:62-75
         if (!(diag0 > 0.0)) return fail(GP_ERR_NOT_PD_DIAG, "not pd: non-positive diagonal elements");
@@ -2175,6 +2258,11 @@ int gp_posterior_samples(gp_t *g, int include_noise, const double *Z, int S, int
         HIPCHK(hipStreamSynchronize(g->s));
         if (sync_words[1] != 0)
             return fail(GP_ERR_HIP, "cooperative tail kernel: grid barrier timed out (a workgroup was not resident)");
+        if (g->emulate_fp64 && info == 0) {
+            int bad = 0;
+            HIPCHK(hipMemcpy(&bad, g->dInfo + 2, sizeof(int), hipMemcpyDeviceToHost));
+            if (bad) return fail(GP_ERR_STATE, "emulate_fp64: an entry of L left the fixed-point range");
+        }
         if (info == 0) break;
         // jitchol: mean(diag) * 1e-6 * 10^k (linalg.py:62-75); the posterior covariance's diagonal is bounded by diag0
         if (!(diag0 > 0.0)) return fail(GP_ERR_NOT_PD_DIAG, "not pd: non-positive diagonal elements");

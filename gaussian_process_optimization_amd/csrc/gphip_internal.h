@@ -144,9 +144,9 @@ void launch_rns_convert(hipStream_t s, const double *src, long ld, long rows, lo
                         long plane_stride, long ldd, double scale, int *flag);
 void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
                         long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int kpanel,
-                        int first);
+                        int first, int tri = 0);
 void launch_rns_reconstruct256(hipStream_t s, const signed char *R, int mt_all, int nt_all, int mt, int c0_128, int c1_128,
-                               long rows, double *T, long ldt, double scale_2e);
+                               long rows, double *T, long ldt, double scale_2e, int tri = 0);
 
 // potrf.hip: cooperative tail of the factorisation (one persistent launch for the trailing tile columns t0 .. nt-1)
 void launch_chol_tail(hipStream_t s, double *A, long lda, double *invL, int *info, int t0, int nt, int R1, unsigned *sync,

@@ -132,6 +132,7 @@ struct RnsGemm256Args {
     int K;                 // multiple of 128
     int kpanel;            // an exact in-register reduction mod p is applied every kpanel bytes of K (<= 896)
     int first;
+    int tri;               // 1: only the tiles with ti >= tc (lower block triangle: the Cholesky's trailing update)
     int sr, sc;            // super-tile counts: 8 row tiles x 4 column tiles each
 };
 
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
     const int sti = (int)(st % nst);
     const int ti = (sti % a.sr) * 8 + (within & 7);
     const int tc = a.c0 + (sti / a.sr) * 4 + (within >> 3);
-    if (ti >= a.mt || tc >= a.c1) return;
+    if (ti >= a.mt || tc >= a.c1 || (a.tri && ti < tc)) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -296,11 +297,11 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
 
 void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
                         long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int kpanel,
-                        int first) {
+                        int first, int tri) {
     if (mt <= 0 || c1 <= c0 || K <= 0) return;
     RnsGemm256Args a;
     a.A = A; a.lda = lda; a.a_plane = a_plane; a.B = B; a.ldb = ldb; a.b_plane = b_plane; a.R = R;
-    a.mt_all = mt_all; a.nt_all = nt_all; a.mt = mt; a.c0 = c0; a.c1 = c1; a.K = K; a.kpanel = kpanel; a.first = first;
+    a.mt_all = mt_all; a.nt_all = nt_all; a.mt = mt; a.c0 = c0; a.c1 = c1; a.K = K; a.kpanel = kpanel; a.first = first; a.tri = tri;
     a.sr = (mt + 7) / 8;
     a.sc = (c1 - c0 + 3) / 4;
     const long nwg = (long)RNS_T * a.sr * a.sc * 32;
@@ -311,13 +312,14 @@ void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_pl
 // 256-column tile); only the 128-column tiles c0_128 .. c1_128 are touched, rows below `rows` only
 __global__ __launch_bounds__(512) void rns_reconstruct256_kernel(const signed char *R, int mt_all, int nt_all, int tc0, int ntc,
                                                                  int c0_128, int c1_128, long rows, double *T, long ldt,
-                                                                 double out_scale) {
+                                                                 double out_scale, int tri) {
     const int blk = blockIdx.x >> 3;   // eight workgroups per 64 KB block: one MFMA tile of each wave's eight per workgroup
     const int ti = blk / ntc, tc = tc0 + blk % ntc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int col128 = (tc * 256 + wn * 64) >> 7;
     if (col128 < c0_128 || col128 >= c1_128) return;   // wave-uniform
+    if (tri && ti < tc) return;                        // block never written (lower block triangle only)
     const long plane = (long)mt_all * nt_all * 65536;
     const signed char *Rb = R + ((long)ti * nt_all + tc) * 65536 + (long)(wave * 8) * 1024 + lane * 16;
     const double MAGIC = 0x1.8p8;  // 1.5 * 2^(52-44): rounds to multiples of 2^-44
@@ -371,12 +373,12 @@ __global__ __launch_bounds__(512) void rns_reconstruct256_kernel(const signed ch
 }
 
 void launch_rns_reconstruct256(hipStream_t s, const signed char *R, int mt_all, int nt_all, int mt, int c0_128, int c1_128,
-                               long rows, double *T, long ldt, double scale_2e) {
+                               long rows, double *T, long ldt, double scale_2e, int tri) {
     if (mt <= 0 || c1_128 <= c0_128) return;
     long double Pl = 1.0L;
     for (int l = 0; l < RNS_T; ++l) Pl *= (long double)h_moduli[l];
     const double P_scaled = (double)(Pl * 0x1p-104L);
     const int tc0 = c0_128 / 2, tc1 = (c1_128 + 1) / 2;
     hipLaunchKernelGGL(rns_reconstruct256_kernel, dim3((unsigned)(8 * mt * (tc1 - tc0))), dim3(512), 0, s, R, mt_all, nt_all, tc0,
-                       tc1 - tc0, c0_128, c1_128, rows, T, ldt, P_scaled * scale_2e);
+                       tc1 - tc0, c0_128, c1_128, rows, T, ldt, P_scaled * scale_2e, tri);
 }

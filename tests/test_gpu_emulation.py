@@ -121,3 +121,79 @@ def test_emulated_headline_configuration_full_size(h):
     assert np.max(np.abs(m1[pick] - mu_o)) <= 1e-6 * np.max(np.abs(mu_o))
     assert np.max(np.abs(v1[pick] - var_o) / var_o) <= 1e-6
     print("emulated candidate solve phases (ms):", ph)
+
+
+@pytest.mark.parametrize("N,D,pt,noise,P", [(1500, 3, 2, 1e-2, 1), (2048, 5, 4, 1e-2, 2), (3000, 8, 6, 1e-2, 1), (2600, 4, 2, 1e-6, 1),
+                                            (4096, 4, 6, 1e-4, 1)])
+def test_emulated_trailing_update_of_the_factorisation(h, N, D, pt, noise, P):
+    """emulate_fp64 also moves the Cholesky's trailing update (the bulk stream's launches) onto the int8 matrix cores:
+    factor, LML, alpha and the posterior against the true-fp64 device path and the oracle."""
+    X, Y, Xs = O.synthetic_problem(N, D, 200, seed=N)
+    if P == 2:
+        Y = np.c_[Y, np.sin(5 * X[:, :1])]
+    h.set_option("panel_tiles", pt)
+    try:
+        h.set_data(X, Y)
+        h.set_params(0, 0, 1.4, [0.25 * np.sqrt(D)], noise)
+        h.set_candidates(Xs)
+        f0 = h.fit()
+        L0, a0 = h.chol(), h.alpha()
+        m0, v0 = h.predict(True)
+        h.set_option("emulate_fp64", 1)
+        f1 = h.fit()
+        L1, a1 = h.chol(), h.alpha()
+        m1, v1 = h.predict(True)
+        assert f1[2] == f0[2]
+        tol = 1e-10 if noise >= 1e-4 else 1e-7      # the stress case amplifies one-ulp operand rounding by cond(Ky) ~ 1e9
+        assert abs(f1[0] - f0[0]) <= max(tol, 1e-12) * abs(f0[0])
+        assert np.max(np.abs(L1 - L0)) <= tol * np.max(np.abs(L0))
+        assert np.max(np.abs(a1 - a0)) <= (1e-8 if noise >= 1e-4 else 1e-5) * np.max(np.abs(a0))
+        assert np.max(np.abs(m1 - m0)) <= (1e-8 if noise >= 1e-4 else 1e-5) * max(1.0, np.max(np.abs(m0)))
+        assert np.max(np.abs(v1 - v0)) <= (1e-8 if noise >= 1e-4 else 1e-6) * 1.4
+        if noise >= 1e-4:
+            gp = O.OracleGP(X, Y, O.RBF(D, 1.4, 0.25 * np.sqrt(D)), noise)
+            p = gp.posterior
+            assert abs(f1[0] - p["lml"]) <= 1e-8 * abs(p["lml"])
+            assert np.max(np.abs(a1 - p["alpha"])) <= 1e-6 * np.max(np.abs(p["alpha"]))
+            mo, vo = gp.predict(Xs)
+            assert relmax(m1, mo) < 1e-6 and np.max(np.abs(v1 - vo) / vo) < 1e-6
+        # gradients on top of an emulated factor
+        g1 = h.lml_grad(1)
+        h.set_option("emulate_fp64", 0)
+        h.fit()
+        g0 = h.lml_grad(1)
+        sc = max(1.0, abs(g0[0]), abs(g0[2]), float(np.max(np.abs(g0[1]))))
+        assert abs(g1[0] - g0[0]) <= 1e-6 * sc and abs(g1[2] - g0[2]) <= 1e-6 * sc and np.max(np.abs(g1[1] - g0[1])) <= 1e-6 * sc
+    finally:
+        h.set_option("emulate_fp64", 0)
+        h.set_option("panel_tiles", 6)
+
+
+def test_emulated_fit_headline_configuration_full_size(h):
+    """C3 with the factorisation's trailing update AND the candidate solve emulated: LML 1e-8, alpha / mean / variance
+    1e-6 against the independent full-size oracle."""
+    from test_gpu_fullsize import _oracle_full_size
+    N, D, M = 16384, 8, 10000
+    X, Y, Xs = O.synthetic_problem(N, D, M, seed=1234)
+    ls = O.default_lengthscale(D, False)
+    h.set_data(X, Y)
+    h.set_params(0, 0, 1.0, ls, 1e-2)
+    h.set_candidates(Xs)
+    h.set_option("emulate_fp64", 1)
+    try:
+        lml, logdet, jit = h.fit()
+        alpha = h.alpha()
+        m1, v1 = h.predict(True)
+        ph = {p["name"]: round(p["ms"], 3) for p in h.phases()}
+        f2, m2, v2 = h.fit_predict(True)
+        assert f2[0] == lml and np.array_equal(m2, m1) and np.array_equal(v2, v1)
+    finally:
+        h.set_option("emulate_fp64", 0)
+    pick = np.unique(np.r_[np.linspace(0, M - 1, 62).astype(int), int(np.argmax(v1)), int(np.argmin(v1))])
+    lml0, logdet0, alpha0, mu_o, var_o = _oracle_full_size(O.RBF(D, 1.0, ls), X, Y, 1e-2, Xs[pick])
+    assert abs(lml - lml0) <= 1e-8 * abs(lml0)
+    assert abs(logdet - logdet0) <= 1e-8 * abs(logdet0)
+    assert np.max(np.abs(alpha - alpha0)) <= 1e-6 * np.max(np.abs(alpha0))
+    assert np.max(np.abs(m1[pick] - mu_o)) <= 1e-6 * np.max(np.abs(mu_o))
+    assert np.max(np.abs(v1[pick] - var_o) / var_o) <= 1e-6
+    print("emulated predict phases (ms):", ph)

@@ -136,23 +136,28 @@ struct RnsGemm256Args {
     int sr, sc;            // super-tile counts: 8 row tiles x 4 column tiles each
 };
 
-// LDS ring of four 32 KB stages (A 256 rows x 64 B, then B 256 rows x 64 B), filled by LDS-DMA (global_load_lds_dwordx4:
-// no staging registers, three stages in flight ~ 1.5 us of cover: with 8 x 4 super-tiles 19 % of the operand requests are
-// first touches that miss L2, and one barrier per stage makes every stage as slow as its slowest line).  LDS-DMA writes a
-// wave instruction's 64 x 16 B linearly, so rows cannot be padded; the 16-byte chunk c of row r is stored in slot
-// c ^ ((r >> 2) & 3) instead (the permutation is applied to the per-lane SOURCE address), which makes the fragment reads
-// (16 rows x one chunk per ds_read_b128 lane group) conflict-free.
-#define R256_STAGE 32768
-
 __device__ __forceinline__ void rns_glds16(const signed char *src, unsigned char *lds_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)lds_uniform, 16, 0, 0);
 }
 
+// K stages of 128 bytes (A 256 rows x 128 B, then B 256 rows x 128 B = 64 KB), double-buffered, filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers; the DMA of stage k+1 is issued at the start of stage k).  LDS-DMA writes
+// a wave instruction's 64 x 16 B linearly, so rows cannot be padded: chunk c of row r sits in slot c ^ ((r >> 1) & 7) (the
+// permutation is applied to the per-lane SOURCE address), which makes the fragment reads -- 16 consecutive rows x one
+// chunk per ds_read_b128 lane group = 16 distinct 16-byte positions of the 256-byte bank row -- conflict-free.
+// Inside a stage the fragments of k step j+1 are read in the MFMA gaps of k step j (one DS read per gap, T19 of the
+// programming guide), and the stage barrier sits before the last k step, so the matrix pipe is busy while the waves
+// synchronise.  Versions measured on the way (C3 candidate solve, ms): 128 x 128 tiles register-staged 37.7 (2 or 4
+// workgroups per CU alike); 256 x 256 register-staged 42.3; LDS-DMA ring of 4 / 5 x 32 KB stages 34.6 / 32.4; this one 31.3.
+// Timing ablations of the ring version (wrong results by construction): no MFMA 26.9, no DMA 34.5, no accumulator traffic
+// 32.8, none of the three 17.1 (11 ms of it this kernel's skeleton: barriers, fragment reads, reductions) -- the costs add
+// up instead of overlapping; a persistent workgroup that prefetches its next tile during the epilogue is the next step.
+#define R256_STAGE 65536
 __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * R256_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R256_STAGE];
     const long nwg = gridDim.x, bid = blockIdx.x;
-    const long wg = (bid & 7) * (nwg >> 3) + (bid >> 3);  // nwg is a multiple of 32
+    const long wg = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int within = (int)(wg & 31);
     const long st = wg >> 5;
     const int nst = a.sr * a.sc;
@@ -166,46 +171,31 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const float p = c_rns.p[l], inv_p = c_rns.inv_p[l];
-
     const signed char *Ag = a.A + (long)l * a.a_plane + (long)ti * 256 * a.lda;
     const signed char *Bg = a.B + (long)l * a.b_plane + (long)tc * 256 * a.ldb;
     signed char *Rb = a.R + (((long)l * a.mt_all + ti) * a.nt_all + tc) * 65536 + (long)(wave * 8) * 1024 + lane * 16;
 
-    // the old residues of the whole tile first (8 x 16 B per lane): oldest in the memory queue, so the first counted
-    // wait of the K loop covers them and their HBM latency overlaps the prologue.  (Loaded tile by tile in the epilogue
-    // they cost 8 serialised round trips per workgroup: the stores in between keep the compiler from batching them.)
-    int4_t cold[8];
+    // DMA map: wave w fills rows w*32 .. w*32+31 of A and of B, four instructions each (8 rows x 128 B per instruction)
+    const signed char *ga[4], *gb[4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) cold[t] = int4_t{0, 0, 0, 0};
-    if (!a.first) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) cold[t] = *(const int4_t *)(Rb + t * 1024);
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 32 + j * 8 + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+        ga[j] = Ag + (long)row * a.lda + ch;
+        gb[j] = Bg + (long)row * a.ldb + ch;
     }
-
-    // DMA map: wave w fills rows w*32 .. w*32+31 of A and of B with two instructions each (16 rows x 64 B per
-    // instruction); lane i -> row + (i >> 2), LDS slot i & 3, source chunk (i & 3) ^ ((row >> 2) & 3)
-    const int drow = wave * 32 + (lane >> 2);
-    const int dch0 = ((lane & 3) ^ ((drow >> 2) & 3)) * 16;           // rows drow and drow + 16 share (row >> 2) & 3 ...
-    const int dch1 = ((lane & 3) ^ (((drow + 16) >> 2) & 3)) * 16;    // ... only when bit 4 does not reach bits 2..3: it does not
-    const signed char *ga0 = Ag + (long)drow * a.lda + dch0;
-    const signed char *ga1 = Ag + (long)(drow + 16) * a.lda + dch1;
-    const signed char *gb0 = Bg + (long)drow * a.ldb + dch0;
-    const signed char *gb1 = Bg + (long)(drow + 16) * a.ldb + dch1;
-    unsigned char *la = smem + wave * 32 * 64;   // wave-uniform
-    const int nk = a.K / 64;
-    const int kred = a.kpanel / 64;
-
+    unsigned char *la = smem + wave * 32 * 128;
+    const int nk = a.K / 128;
+    const int kred = a.kpanel / 128;
     auto issue = [&](int kt) {
-        unsigned char *sb = la + (kt & 3) * R256_STAGE;
-        const long ko = (long)kt * 64;
-        rns_glds16(ga0 + ko, sb);
-        rns_glds16(ga1 + ko, sb + 1024);
-        rns_glds16(gb0 + ko, sb + 16384);
-        rns_glds16(gb1 + ko, sb + 16384 + 1024);
+        unsigned char *sb = la + (kt & 1) * R256_STAGE;
+        const long ko = (long)kt * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rns_glds16(ga[j] + ko, sb + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rns_glds16(gb[j] + ko, sb + 32768 + j * 1024);
     };
     issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
 
     int16v_t acc[4][2];
 #pragma unroll
@@ -215,56 +205,73 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
 
-    // fragment reads: row (lane & 31) of the MFMA tile, logical chunk 2 ks + (lane >> 5), slot = chunk ^ ((row >> 2) & 3)
     const int frow = lane & 31, fh = lane >> 5;
-    int aoffs[4][2], boffs[2][2];
+    int arow[4], brow[2], asw[4], bsw[2];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int r = wm * 128 + m * 32 + frow;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) aoffs[m][ks] = r * 64 + (((2 * ks + fh) ^ ((r >> 2) & 3)) * 16);
+        arow[m] = r * 128;
+        asw[m] = (r >> 1) & 7;
     }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int r = wn * 64 + n * 32 + frow;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) boffs[n][ks] = 16384 + r * 64 + (((2 * ks + fh) ^ ((r >> 2) & 3)) * 16);
+        brow[n] = 32768 + r * 128;
+        bsw[n] = (r >> 1) & 7;
     }
-
+    int4_t fa[2][4], fb[2][2];
+    auto read_frags = [&](int set, int ks, int kt) {
+        const unsigned char *sb = smem + (kt & 1) * R256_STAGE;
+        const int c = 2 * ks + fh;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[set][m] = *(const int4_t *)(sb + arow[m] + ((c ^ asw[m]) << 4));
+#pragma unroll
+        for (int n = 0; n < 2; ++n) fb[set][n] = *(const int4_t *)(sb + brow[n] + ((c ^ bsw[n]) << 4));
+    };
+    auto mfma_step = [&](int set) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][m], fb[set][n], acc[m][n], 0, 0, 0);
+    };
+    auto interleave6 = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        // this wave's DMA of stage kt has landed once at most the two younger stages' are outstanding
-        const int younger = nk - 1 - kt;
-        if (younger >= 2)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // ... and every other wave's; all waves are also done reading stage kt-1
+        const bool next = kt + 1 < nk;
+        if (next) issue(kt + 1);   // the other buffer: every wave left it at the previous barrier, its reads retired
+        read_frags(1, 1, kt);
+        mfma_step(0);
+        interleave6();
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned char *sb = smem + (kt & 3) * R256_STAGE;
-        // fragments of both k steps are requested before the first MFMA; the DMA of stage kt+3 (into the buffer of stage
-        // kt-1) is issued between the two groups of reads, behind the LDS latency of the first
-        int4_t af[2][4], bf[2][2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) af[0][m] = *(const int4_t *)(sb + aoffs[m][0]);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) bf[0][n] = *(const int4_t *)(sb + boffs[n][0]);
-        if (kt + 3 < nk) issue(kt + 3);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) af[1][m] = *(const int4_t *)(sb + aoffs[m][1]);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) bf[1][n] = *(const int4_t *)(sb + boffs[n][1]);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][m], bf[ks][n], acc[m][n], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if ((kt + 1) % kred == 0 && kt + 1 < nk) {   // panel boundary inside one launch: keep the sums below 2^24
+        read_frags(0, 2, kt);
+        mfma_step(1);
+        interleave6();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(1, 3, kt);
+        mfma_step(0);
+        interleave6();
+        __builtin_amdgcn_sched_barrier(0);
+        if (next) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // stage kt+1 landed; this wave's reads of stage kt retired
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(0, 0, kt + 1);
+        }
+        mfma_step(1);
+        if (next) interleave6();
+        __builtin_amdgcn_sched_barrier(0);
+        if ((kt + 1) % kred == 0 && next) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -273,8 +280,13 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
                     for (int r = 0; r < 16; ++r) acc[m][n][r] = mod_sym(acc[m][n][r], p, inv_p);
         }
     }
-
-    // epilogue: (old + sum) mod p, 16 bytes per lane per MFMA tile
+    int4_t cold[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) cold[t] = int4_t{0, 0, 0, 0};
+    if (!a.first) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cold[t] = *(const int4_t *)(Rb + t * 1024);
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll

@@ -438,7 +438,9 @@ def test_one_call_fit_predict_path_in_the_host_mirror():
     assert m._dirty
     mu1, v1 = m.predict(Xs)                 # one call
     names = [p["name"] for p in m._h.phases()]
-    assert any("cholesky+cand_solve" in n for n in names) and not m._dirty
+    # the pipelined entry point (true fp64: one phase "cholesky+cand_solve") or, with GPHIP_EMULATE_FP64=1, the
+    # factorisation followed by the emulated solve (the phases of the last call, gp_predict, are what is left)
+    assert any("cand_solve" in n for n in names) and not m._dirty
     m.kern.lengthscale[:] = 0.45
     m._dirty = True
     lml = m.log_likelihood()                # explicit fit ...

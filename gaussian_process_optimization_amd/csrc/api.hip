@@ -125,6 +125,7 @@ struct gp_ctx {
     int chain_small_below = 400;  // ... the same threshold for the launches of the factorisation's chain stream
     int lauum_panels = 1;    // Ky^-1 product accumulated per k-panel (0: one launch over the whole contraction)
     int side_alpha = 1;      // alpha / log det on the side stream while stages of the one-call entry points still run
+    int pair_panels = 1;     // candidate solve: two panels per update launch (K = 2 x panel width), bitwise the same result
     int pair_tri = 2;        // triangular-K products: pair column tiles c and W-1-c in one workgroup (1: 64x64 units only)
     int fmin_direct = 0;     // gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha
     int inner_left_rows = 1 << 30;  // panels with at least this many row tiles update their columns left-looking
@@ -530,6 +531,8 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->wi_valid = false;
     } else if (!strcmp(name, "side_alpha")) {
         g->side_alpha = (int)value;
+    } else if (!strcmp(name, "pair_panels")) {
+        g->pair_panels = value ? 1 : 0;
     } else if (!strcmp(name, "pair_tri")) {
         g->pair_tri = (int)value;
     } else if (!strcmp(name, "fmin_direct")) {
@@ -1066,20 +1069,39 @@ static void solve_rows(gp_ctx *g, double *T, double *S, int mt, int trapezoid, i
     const long PB = (long)W * GP_TILE;
     const double *L = g->dA;
     hipStream_t s = g->s;
-    for (int J0 = J_from * W, J = J_from; J0 < nt; J0 += W, ++J) {
-        const int J1 = std::min(J0 + W, nt);
-        const int Kp = (J1 - J0) * GP_TILE;
-        const int rows = trapezoid ? std::min(mt, J1) : mt;
+    auto panel_solve = [&](int J, int J0, int J1, int rows) {
         GemmOpt o;
         o.k_end_tri = 1;
         o.b_sub = J0;
         // S[:, J] = T[:, J] invP_J^T   (invP_J lower triangular: column tile c contracts k <= c)
-        gemm(g, s, 0, S, Npad, T + (long)J0 * GP_TILE, Npad, g->dInvP + (long)J * PB * PB, PB, 1, Kp,
+        gemm(g, s, 0, S, Npad, T + (long)J0 * GP_TILE, Npad, g->dInvP + (long)J * PB * PB, PB, 1, (J1 - J0) * GP_TILE,
              TileSet{0, rows, J0, J1, 0}, o);
-        // T[:, > J] -= S[:, J] L[> J, J]^T
-        if (J1 < nt)
+    };
+    for (int J0 = J_from * W, J = J_from; J0 < nt;) {
+        const int J1 = std::min(J0 + W, nt), J2 = std::min(J1 + W, nt);
+        const int Kp = (J1 - J0) * GP_TILE;
+        const int rows = trapezoid ? std::min(mt, J1) : mt;
+        panel_solve(J, J0, J1, rows);
+        if (J1 >= nt) break;
+        // Two panels per update (full row sets only): panel J+1's columns take panel J's update as a small launch of
+        // their own, then ONE launch contracts both panels (K = 2 PB) into everything right of them -- half the round
+        // trips of the running right-hand side through HBM and a contraction twice as long.  The accumulator sees the
+        // same products in the same order as with one launch per panel: bitwise the same result.
+        const bool two = g->pair_panels && !trapezoid && J2 > J1 && J2 < nt;
+        if (!two) {
+            // T[:, > J] -= S[:, J] L[> J, J]^T
             gemm(g, s, 1, T, Npad, S + (long)J0 * GP_TILE, Npad, L + (long)J0 * GP_TILE, lda, 1, Kp,
                  TileSet{0, rows, J1, nt, 0});
+            J0 = J1;
+            ++J;
+            continue;
+        }
+        gemm(g, s, 1, T, Npad, S + (long)J0 * GP_TILE, Npad, L + (long)J0 * GP_TILE, lda, 1, Kp, TileSet{0, rows, J1, J2, 0});
+        panel_solve(J + 1, J1, J2, rows);
+        gemm(g, s, 1, T, Npad, S + (long)J0 * GP_TILE, Npad, L + (long)J0 * GP_TILE, lda, 1, (J2 - J0) * GP_TILE,
+             TileSet{0, rows, J2, nt, 0});
+        J0 = J2;
+        J += 2;
     }
 }
 

@@ -157,6 +157,7 @@ struct gp_ctx {
     unsigned *dSync = nullptr;
     int emulate_fp64 = 0;
     int rns_pair = 1;  // two panels per residue launch
+    int rns_pad = 0;   // bytes added to the row pitch of L's residue planes (measured: no effect)
     signed char *dLr = nullptr, *dSr = nullptr, *dRr = nullptr;  // residue planes of L, of the current S panel, accumulator
     signed char *dRm = nullptr;                                   // residue accumulator of the trailing matrix (factorisation)
     long capLr = 0, capSr = 0, capRr = 0, capRm = 0;
@@ -568,6 +569,11 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "tail_wgs")) {
         if (value < 0 || value > 1024) return fail(GP_ERR_ARG, "tail_wgs out of range");
         g->tail_wgs = (int)value;
+    } else if (!strcmp(name, "rns_pad")) {
+        if (value < 0 || value % 16) return fail(GP_ERR_ARG, "rns_pad must be a non-negative multiple of 16");
+        g->rns_pad = (int)value;
+        g->lr_valid = false;
+        if (g->dLr) { hipFree(g->dLr); g->dLr = nullptr; g->capLr = 0; }
     } else if (!strcmp(name, "rns_pair")) {
         g->rns_pair = value ? 1 : 0;
     } else if (!strcmp(name, "emulate_fit")) {
@@ -776,7 +782,7 @@ static int byte_realloc(signed char **p, long *cap, long need) {
 struct RnsGeom {
     int e = 0;
     double scale = 1.0, back = 1.0;
-    long Lrows = 0, Lplane = 0;
+    long Lrows = 0, Lplane = 0, Lpitch = 0;   // row pitch of the residue planes of L in bytes: NOT a power of two
     int nt256 = 0;
 };
 
@@ -788,7 +794,10 @@ static int rns_prepare(gp_ctx *g, double jitter, RnsGeom *r) {
     if (g->N > (1L << 20)) return fail(GP_ERR_ARG, "emulate_fp64 needs N <= 2^20");
     if (rns_init_constants(g->device)) return fail(GP_ERR_HIP, "rns constants");
     r->Lrows = round_up(Npad, 256);
-    r->Lplane = r->Lrows * Npad;
+    // a row pitch of exactly Npad bytes (a power of two at the benchmark sizes) would put the 256 rows of an operand
+    // tile's K slice on the same memory channel
+    r->Lpitch = Npad + g->rns_pad;
+    r->Lplane = r->Lrows * r->Lpitch;
     r->nt256 = (int)(r->Lrows / 256);
     // common power-of-two scale: |L_ij| <= sqrt(max diag of Ky), |S_ik| <= sqrt(prior variance); one spare bit
     const double diag0 = (g->kp.gower ? std::pow(g->kp.variance, g->D) : g->kp.variance) + g->noise + 1e-8 + jitter;
@@ -806,7 +815,7 @@ static int rns_prepare(gp_ctx *g, double jitter, RnsGeom *r) {
         g->lr_valid = false;
     }
     const int nJ = (nt + W - 1) / W;
-    if (!g->lr_valid || g->lr_W != W || g->lr_e != e || (int)g->lr_done.size() != nJ) {
+    if (!g->lr_valid || g->lr_W != W || g->lr_e != e || (int)g->lr_done.size() != nJ) {   // (rns_pad frees dLr)
         g->lr_done.assign(nJ, 0);
         g->lr_W = W;
         g->lr_e = e;
@@ -822,7 +831,7 @@ static void rns_convert_panel(gp_ctx *g, hipStream_t s, const RnsGeom &r, int J,
     const int J0 = J * W, J1 = std::min(J0 + W, nt);
     if (J1 >= nt || g->lr_done[J]) return;
     launch_rns_convert(s, g->dA + (long)J1 * GP_TILE * lda + (long)J0 * GP_TILE, lda, Npad - (long)J1 * GP_TILE,
-                       (long)(J1 - J0) * GP_TILE, g->dLr + (long)J1 * GP_TILE * Npad + (long)J0 * GP_TILE, r.Lplane, Npad,
+                       (long)(J1 - J0) * GP_TILE, g->dLr + (long)J1 * GP_TILE * r.Lpitch + (long)J0 * GP_TILE, r.Lplane, r.Lpitch,
                        r.scale, flag);
     g->lr_done[J] = 1;
 }
@@ -953,7 +962,7 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
             hipStreamWaitEvent(sb, eF, 0);
             if (emu) {
                 rns_convert_panel(g, sb, rg, J, rflag);
-                launch_rns_gemm256(sb, g->dLr + (long)J0 * GP_TILE, g->Npad, rg.Lplane, g->dLr + (long)J0 * GP_TILE, g->Npad,
+                launch_rns_gemm256(sb, g->dLr + (long)J0 * GP_TILE, rg.Lpitch, rg.Lplane, g->dLr + (long)J0 * GP_TILE, rg.Lpitch,
                                    rg.Lplane, g->dRm, rg.nt256, rg.nt256, rg.nt256, J2 / 2, rg.nt256, K, K, J == 0 ? 1 : 0, 1);
                 // the right-hand-side tile row rides in fp64
                 gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
@@ -1156,7 +1165,7 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
         launch_rns_convert(s, S + (long)J0 * GP_TILE, Npad, Mcpad, K0, g->dSr, Splane, KS, scale, flag);
         const bool two = pair && J2 > J1 && J2 < nt;
         if (!two) {
-            launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, Npad, Lplane, g->dRr, mt256, nt256, mt256,
+            launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256, mt256,
                                J1 / 2, nt256, K0, K0, first ? 1 : 0);
             first = false;
             J0 = J1;
@@ -1164,7 +1173,7 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
             continue;
         }
         // panel J -> the columns of panel J+1 only (256-column tiles that overlap [J1, J2))
-        launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, Npad, Lplane, g->dRr, mt256, nt256, mt256,
+        launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256, mt256,
                            J1 / 2, (J2 + 1) / 2, K0, K0, first ? 1 : 0);
         launch_rns_reconstruct256(s, g->dRr, mt256, nt256, mt256, J1, J2, Mcpad, T, Npad, back);
         panel_solve(J1, J2, J + 1);
@@ -1173,7 +1182,7 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
         // panel J's update in its left half from the small launch: those columns are final and never read again, its
         // right half must not get panel J twice -- so the small launch stops at the tile boundary below J2 and this
         // one starts there when J2 is odd.
-        launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, Npad, Lplane, g->dRr, mt256, nt256, mt256,
+        launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256, mt256,
                            (J2 + 1) / 2, nt256, K0 + K1, K0, first ? 1 : 0);
         first = false;
         J0 = J2;

@@ -152,7 +152,10 @@ __device__ __forceinline__ void rns_glds16(const signed char *src, unsigned char
 // workgroups per CU alike); 256 x 256 register-staged 42.3; LDS-DMA ring of 4 / 5 x 32 KB stages 34.6 / 32.4; this one 31.3.
 // Timing ablations of the ring version (wrong results by construction): no MFMA 26.9, no DMA 34.5, no accumulator traffic
 // 32.8, none of the three 17.1 (11 ms of it this kernel's skeleton: barriers, fragment reads, reductions) -- the costs add
-// up instead of overlapping; a persistent workgroup that prefetches its next tile during the epilogue is the next step.
+// up instead of overlapping.  Also measured and dropped: the same product as 4-wave workgroups on 128 x 256 tiles, two
+// independent workgroups per CU (33.0 ms), and a row pitch of the L planes off the power of two (no change): neither
+// barrier lockstep nor channel conflicts are the limiter.  All variants sit at 1.5-1.7 Pop/s, the level the programming
+// guide quotes for its simple two-barrier bf16 loop (36 % of peak); its 8-phase schedule is the known way beyond.
 #define R256_STAGE 65536
 __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R256_STAGE];
@@ -173,7 +176,10 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
     const float p = c_rns.p[l], inv_p = c_rns.inv_p[l];
     const signed char *Ag = a.A + (long)l * a.a_plane + (long)ti * 256 * a.lda;
     const signed char *Bg = a.B + (long)l * a.b_plane + (long)tc * 256 * a.ldb;
-    signed char *Rb = a.R + (((long)l * a.mt_all + ti) * a.nt_all + tc) * 65536 + (long)(wave * 8) * 1024 + lane * 16;
+    // accumulator sub-blocks of this wave: rb = wm * 4 + m, cb = wn * 2 + n; tile t = m * 2 + n sits at Rb + RBOFF(t)
+    signed char *Rb = a.R + (((long)l * a.mt_all + ti) * a.nt_all + tc) * 65536 + lane * 16;
+    const int rb0 = wm * 4, cb0 = wn * 2;
+#define RBOFF(t) ((((rb0 + ((t) >> 1)) * 8) + cb0 + ((t) & 1)) * 1024)
 
     // DMA map: wave w fills rows w*32 .. w*32+31 of A and of B, four instructions each (8 rows x 128 B per instruction)
     const signed char *ga[4], *gb[4];
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
     for (int t = 0; t < 8; ++t) cold[t] = int4_t{0, 0, 0, 0};
     if (!a.first) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) cold[t] = *(const int4_t *)(Rb + t * 1024);
+        for (int t = 0; t < 8; ++t) cold[t] = *(const int4_t *)(Rb + RBOFF(t));
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -303,8 +309,9 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
                 }
                 out[w] = (int)packed;
             }
-            *(int4_t *)(Rb + t * 1024) = out;
+            *(int4_t *)(Rb + RBOFF(t)) = out;
         }
+#undef RBOFF
 }
 
 void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
@@ -333,18 +340,19 @@ __global__ __launch_bounds__(512) void rns_reconstruct256_kernel(const signed ch
     if (col128 < c0_128 || col128 >= c1_128) return;   // wave-uniform
     if (tri && ti < tc) return;                        // block never written (lower block triangle only)
     const long plane = (long)mt_all * nt_all * 65536;
-    const signed char *Rb = R + ((long)ti * nt_all + tc) * 65536 + (long)(wave * 8) * 1024 + lane * 16;
+    const signed char *Rb = R + ((long)ti * nt_all + tc) * 65536 + lane * 16;
     const double MAGIC = 0x1.8p8;  // 1.5 * 2^(52-44): rounds to multiples of 2^-44
     {
         const int t = blockIdx.x & 7;
         const int m = t >> 1, n = t & 1;
+        const int sub = ((wm * 4 + m) * 8 + wn * 2 + n) * 1024;   // sub-block (rb, cb) = (wm*4 + m, wn*2 + n)
         const long row0 = (long)ti * 256 + wm * 128 + m * 32 + 4 * (lane >> 5);
         if ((long)ti * 256 + wm * 128 + m * 32 >= rows) return;   // wave-uniform
         // everything this tile needs is requested before any of it is used: the 16 residue vectors and the 16 fp64
         // values of T to be updated (one batch of loads instead of 32 dependent round trips)
         int4_t v[RNS_T];
 #pragma unroll
-        for (int l = 0; l < RNS_T; ++l) v[l] = *(const int4_t *)(Rb + l * plane + t * 1024);
+        for (int l = 0; l < RNS_T; ++l) v[l] = *(const int4_t *)(Rb + l * plane + sub);
         const long col = (long)tc * 256 + wn * 64 + n * 32 + (lane & 31);
         double told[16];
 #pragma unroll

@@ -20,7 +20,7 @@ for emu, variant, dbg in ((0, 1, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (1, 0, 0),
         mu, var = h.predict(True)
     h.synchronize(); dt = (time.perf_counter() - t0) / 3 * 1e3
     ph = {p["name"]: round(p["ms"], 3) for p in h.phases()}
-    print("emulate_fp64=%d pair %d dbg %d  predict %.2f ms  (%.1f TFLOP/s fp64-equivalent)  phases %s" % (emu, variant, dbg, dt, float(N) * N * M / dt / 1e9, ph))
+    print("emulate_fp64=%d pair %d (%d)  predict %.2f ms  (%.1f TFLOP/s fp64-equivalent)  phases %s" % (emu, variant, dbg, dt, float(N) * N * M / dt / 1e9, ph))
     if emu == 0: ref = (mu.copy(), var.copy())
     else: print("   max |mean diff| %.2e   max rel var diff %.2e" % (np.max(np.abs(mu - ref[0])), np.max(np.abs(var - ref[1]) / ref[1])))
 h.close()

@@ -156,7 +156,7 @@ struct gp_ctx {
     int ncu = 0;
     unsigned *dSync = nullptr;
     int emulate_fp64 = 0;
-    int rns_pair = 1;  // two panels per residue launch
+    int rns_group = 8; // panels per residue launch of the emulated candidate solve
     int rns_pad = 0;   // bytes added to the row pitch of L's residue planes (measured: no effect)
     signed char *dLr = nullptr, *dSr = nullptr, *dRr = nullptr;  // residue planes of L, of the current S panel, accumulator
     signed char *dRm = nullptr;                                   // residue accumulator of the trailing matrix (factorisation)
@@ -574,8 +574,9 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->rns_pad = (int)value;
         g->lr_valid = false;
         if (g->dLr) { hipFree(g->dLr); g->dLr = nullptr; g->capLr = 0; }
-    } else if (!strcmp(name, "rns_pair")) {
-        g->rns_pair = value ? 1 : 0;
+    } else if (!strcmp(name, "rns_group")) {
+        if (value < 1 || value > 16) return fail(GP_ERR_ARG, "rns_group must be in [1, 16]");
+        g->rns_group = (int)value;
     } else if (!strcmp(name, "emulate_fit")) {
         g->emulate_fit = value ? 1 : 0;
     } else if (!strcmp(name, "emulate_fp64")) {
@@ -790,7 +791,7 @@ static int rns_prepare(gp_ctx *g, double jitter, RnsGeom *r) {
     const long Npad = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
     const int W = std::min(g->panel_tiles, nt);
-    if ((long)W * GP_TILE > 896) return fail(GP_ERR_ARG, "emulate_fp64 needs panel_tiles <= 7 (int32 sums must stay below 2^24)");
+    if ((long)W * GP_TILE > GP_RNS_KMAX) return fail(GP_ERR_ARG, "emulate_fp64: panel_tiles too wide for one residue contraction");
     if (g->N > (1L << 20)) return fail(GP_ERR_ARG, "emulate_fp64 needs N <= 2^20");
     if (rns_init_constants(g->device)) return fail(GP_ERR_HIP, "rns constants");
     r->Lrows = round_up(Npad, 256);
@@ -880,7 +881,7 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     // (rns.hip).  The Schur complement right of the look-ahead panel lives as Ky (untouched, in dA) minus an exact integer
     // accumulator dRm; a panel's columns are rebuilt in fp64 once, right before they become the look-ahead target.  The
     // chain (diagonal tiles, panel solves, in-panel and look-ahead updates) and the right-hand-side tile row stay fp64.
-    const bool emu = g->emulate_fp64 && g->emulate_fit && (PB % 256 == 0) && PB <= 896 &&
+    const bool emu = g->emulate_fp64 && g->emulate_fit && (PB % 256 == 0) && PB <= GP_RNS_KMAX &&
                      !(g->panel_tiles_tail > 0) && !(g->tail_tiles > 0);
     RnsGeom rg;
     int *rflag = g->dInfo + 2;
@@ -963,7 +964,7 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
             if (emu) {
                 rns_convert_panel(g, sb, rg, J, rflag);
                 launch_rns_gemm256(sb, g->dLr + (long)J0 * GP_TILE, rg.Lpitch, rg.Lplane, g->dLr + (long)J0 * GP_TILE, rg.Lpitch,
-                                   rg.Lplane, g->dRm, rg.nt256, rg.nt256, rg.nt256, J2 / 2, rg.nt256, K, K, J == 0 ? 1 : 0, 1);
+                                   rg.Lplane, g->dRm, rg.nt256, rg.nt256, rg.nt256, J2 / 2, rg.nt256, K, J == 0 ? 1 : 0, 1);
                 // the right-hand-side tile row rides in fp64
                 gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
                      TileSet{nt, R1, J2, nt, 0});
@@ -1124,9 +1125,17 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
     if (W != std::min(g->panel_tiles, nt)) return fail(GP_ERR_STATE, "emulate_fp64: panel width changed since the fit");
     if ((rc = rns_prepare(g, g->jitter, &r))) return rc;
     // 256 x 256 workgroup tiles: rows / columns padded to multiples of 256 (zero residues in the padding)
-    const long Mc256 = round_up(Mcpad, 256), Lrows = r.Lrows;
+    const long Mc256 = round_up(Mcpad, 256);
     const int mt256 = (int)(Mc256 / 256), nt256 = r.nt256;
-    const long KS = 2 * PB;   // up to two panels of S side by side (one launch then contracts both)
+    // Panels are taken in groups of G (option "rns_group"): their S panels sit side by side in the residue buffer, the
+    // columns of group panel i take ONE launch that contracts the i panels before it (K = i PB), and ONE launch then
+    // contracts the whole group (K = G PB) into every column right of it.  Each accumulator block is therefore read,
+    // reduced and written once per group instead of once per panel, and the contraction is G times as long; the
+    // products summed are the same integers, so the result does not depend on G.  Panel edges must sit on 256-column
+    // accumulator blocks for the launches of one group to touch disjoint blocks: odd panel widths take G = 1.
+    int G = std::max(1, std::min(g->rns_group, (int)(GP_RNS_KMAX / PB)));
+    if (W % 2) G = 1;
+    const long KS = G * PB;
     auto zalloc = [&](signed char **p, long *cap, long need) -> int {
         if (need <= *cap && *p) return 0;
         int r2 = byte_realloc(p, cap, need);
@@ -1134,7 +1143,7 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
         if (hipMemsetAsync(*p, 0, (size_t)need, g->s) != hipSuccess) return fail(GP_ERR_HIP, "hipMemsetAsync");
         return 0;
     };
-    (void)Lrows;
+    if (PB > GP_RNS_KMAX) return fail(GP_ERR_ARG, "emulate_fp64: panel_tiles too wide for one residue contraction");
     if ((rc = zalloc(&g->dSr, &g->capSr, (long)GP_RNS_T * Mc256 * KS))) return rc;
     if ((rc = zalloc(&g->dRr, &g->capRr, (long)GP_RNS_T * mt256 * nt256 * 65536))) return rc;
     hipStream_t s = g->s;
@@ -1144,49 +1153,38 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
     const double scale = r.scale, back = r.back;
     const long Lplane = r.Lplane, Splane = Mc256 * KS;
     for (int J = 0; J < (int)g->lr_done.size(); ++J) rns_convert_panel(g, s, r, J, flag);
-    // Panels are taken in pairs (J, J+1): panel J+1's columns receive panel J's update as a small launch of their own,
-    // then ONE launch contracts both panels (K = 2 PB, an exact reduction mod p between the halves) into every column
-    // further right -- half the round trips of the residue accumulator through HBM.
-    const int pair = g->rns_pair;
-    bool first = true;
+    auto panel_solve = [&](int Ja, int Jb, int Jidx) {   // S[:, Ja..Jb) = T[:, Ja..Jb) invP^T, fp64
+        GemmOpt o;
+        o.k_end_tri = 1;
+        o.b_sub = Ja;
+        gemm(g, s, 0, S, Npad, T + (long)Ja * GP_TILE, Npad, g->dInvP + (long)Jidx * PB * PB, PB, 1, (Jb - Ja) * GP_TILE,
+             TileSet{0, mt, Ja, Jb, 0}, o);
+    };
+    bool first = true;   // no launch has written the accumulator yet: the first group's launches overwrite their blocks
     for (int J0 = 0, J = 0; J0 < nt;) {
-        const int J1 = std::min(J0 + W, nt), J2 = std::min(J1 + W, nt);
-        const int K0 = (J1 - J0) * GP_TILE, K1 = (J2 - J1) * GP_TILE;
-        auto panel_solve = [&](int Ja, int Jb, int Jidx) {   // S[:, Ja..Jb) = T[:, Ja..Jb) invP^T, fp64
-            GemmOpt o;
-            o.k_end_tri = 1;
-            o.b_sub = Ja;
-            gemm(g, s, 0, S, Npad, T + (long)Ja * GP_TILE, Npad, g->dInvP + (long)Jidx * PB * PB, PB, 1, (Jb - Ja) * GP_TILE,
-                 TileSet{0, mt, Ja, Jb, 0}, o);
-        };
-        if (!first) launch_rns_reconstruct256(s, g->dRr, mt256, nt256, mt256, J0, J1, Mcpad, T, Npad, back);
-        panel_solve(J0, J1, J);
-        if (J1 >= nt) break;
-        launch_rns_convert(s, S + (long)J0 * GP_TILE, Npad, Mcpad, K0, g->dSr, Splane, KS, scale, flag);
-        const bool two = pair && J2 > J1 && J2 < nt;
-        if (!two) {
-            launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256, mt256,
-                               J1 / 2, nt256, K0, K0, first ? 1 : 0);
-            first = false;
-            J0 = J1;
-            ++J;
-            continue;
+        int done = 0;    // panels of this group solved and converted; they span tiles [J0, Ja)
+        bool last = false;
+        for (int i = 0; i < G; ++i) {
+            const int Ja = J0 + i * W, Jb = std::min(Ja + W, nt);
+            if (Ja >= nt) break;
+            if (i > 0)   // the group's earlier panels -> this panel's columns (whole 256-column blocks: Ja, Jb are even)
+                launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256,
+                                   mt256, Ja / 2, (Jb + 1) / 2, (Ja - J0) * GP_TILE, first ? 1 : 0);
+            if (!first || i > 0) launch_rns_reconstruct256(s, g->dRr, mt256, nt256, mt256, Ja, Jb, Mcpad, T, Npad, back);
+            panel_solve(Ja, Jb, J + i);
+            done = i + 1;
+            if (Jb >= nt) { last = true; break; }
+            launch_rns_convert(s, S + (long)Ja * GP_TILE, Npad, Mcpad, (Jb - Ja) * GP_TILE, g->dSr + (long)i * PB, Splane, KS, scale,
+                               flag);
         }
-        // panel J -> the columns of panel J+1 only (256-column tiles that overlap [J1, J2))
+        if (last) break;
+        const int Jg = J0 + done * W;   // < nt here
+        // the whole group -> every column right of it
         launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256, mt256,
-                           J1 / 2, (J2 + 1) / 2, K0, K0, first ? 1 : 0);
-        launch_rns_reconstruct256(s, g->dRr, mt256, nt256, mt256, J1, J2, Mcpad, T, Npad, back);
-        panel_solve(J1, J2, J + 1);
-        launch_rns_convert(s, S + (long)J1 * GP_TILE, Npad, Mcpad, K1, g->dSr + K0, Splane, KS, scale, flag);
-        // both panels -> every column right of panel J+1.  The tile column that straddles J2 (odd J2) already holds
-        // panel J's update in its left half from the small launch: those columns are final and never read again, its
-        // right half must not get panel J twice -- so the small launch stops at the tile boundary below J2 and this
-        // one starts there when J2 is odd.
-        launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256, mt256,
-                           (J2 + 1) / 2, nt256, K0 + K1, K0, first ? 1 : 0);
+                           G == 1 ? Jg / 2 : (Jg + 1) / 2, nt256, (Jg - J0) * GP_TILE, first ? 1 : 0);
         first = false;
-        J0 = J2;
-        J += 2;
+        J0 = Jg;
+        J += done;
     }
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1954,7 +1952,7 @@ static int wi_lauum(gp_ctx *g) {
 static int ensure_wi(gp_ctx *g) {
     if (g->wi_valid) return 0;
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
-    const long Npad = g->Npad, lda = g->Npad;
+    const long Npad = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
     int rc;
     if ((rc = ensure_panel_inv(g))) return rc;

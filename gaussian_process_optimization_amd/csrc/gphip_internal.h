@@ -139,11 +139,12 @@ void launch_zero_upper_diag(hipStream_t s, double *A, long lda, int nt);
 
 // ---- rns.hip: fp64-equivalent contraction on the int8 matrix cores (option "emulate_fp64") -----------------------------
 #define GP_RNS_T 16
+#define GP_RNS_KMAX 8192   // longest contraction (bytes) one residue launch may take: see rns_reduce_f in rns.hip
 int rns_init_constants(int device);
 void launch_rns_convert(hipStream_t s, const double *src, long ld, long rows, long cols, signed char *dst,
                         long plane_stride, long ldd, double scale, int *flag);
 void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
-                        long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int kpanel,
+                        long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K,
                         int first, int tri = 0);
 void launch_rns_reconstruct256(hipStream_t s, const signed char *R, int mt_all, int nt_all, int mt, int c0_128, int c1_128,
                                long rows, double *T, long ldt, double scale_2e, int tri = 0);

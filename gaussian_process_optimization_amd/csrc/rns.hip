@@ -7,7 +7,7 @@
 //   * operands |x| < 2^e are fixed-point integers v = rint(x 2^(52-e)) (exact in fp64), stored as their symmetric residues
 //     v mod p_l (int8) for 16 pairwise coprime moduli p_l <= 253, P = prod p_l ~ 2^125.1;
 //   * T[:, c] -= sum_J S_J L[c, J]^T (the running right-hand side of dtrtrs, posterior.py:294) becomes, per modulus, an int8
-//     GEMM whose int32 sums are reduced mod p_l and added to an int8 residue accumulator R_l -- no rounding anywhere;
+//     GEMM whose int32 sums are reduced mod p_l and added to a one-byte residue accumulator R_l -- no rounding anywhere;
 //   * before panel c of T is needed in fp64 (for the product with the inverted diagonal panel) the exact integer
 //     X = sum a b (|X| < N 2^104 < P/2) is recovered from its 16 residues by the CRT in fraction form,
 //     X / P = centred_frac(sum_l w_l / p_l), w_l = r_l q_l mod p_l, with two fp64 accumulators (terms rounded to
@@ -109,10 +109,21 @@ void launch_rns_convert(hipStream_t s, const double *src, long ld, long rows, lo
     hipLaunchKernelGGL(rns_convert_kernel, grid, dim3(256), 0, s, src, ld, rows, cols4, dst, plane_stride, ldd, scale, flag);
 }
 
-__device__ __forceinline__ int mod_sym(int s, float p, float inv_p) {
-    const float f = (float)s;                 // |s| < 2^24: exact
-    const float q = rintf(f * inv_p);
-    return (int)fmaf(-q, p, f);               // exact remainder, |r| <= 127 (see h_moduli)
+// Accumulator residues are stored as UNSIGNED bytes, any representative in [0, p + 2] (<= 255): the accumulator is never
+// an MFMA operand, and v_cvt_f32_ubyteN / v_cvt_pk_u8_f32 then unpack and pack a byte in one instruction each.
+//   fold: s = hi 2^12 + lo (arithmetic shift, lo in [0, 4095])  ->  t = hi (4096 mod p) + lo = s (mod p) with
+//   |t| <= |s| / 16 + 4096: three integer instructions bring ANY sum of a contraction of up to GP_RNS_KMAX = 8192 bytes
+//   (|s| <= 8192 * 127^2 < 2^27) below 2^23.1, so one launch may contract several panels with NO intermediate reduction;
+//   reduce: f = t + old byte (exact in f32); the f32 product f * (1/p) is off by at most 1.5 * 2^-24 * |f| / p < 0.004
+//   (|f| / p < 2^23.1 / 191), so q = floor(f / p - 0.006) never exceeds the true quotient and falls short of it by one
+//   only when the remainder is below 0.01 p < 2.6: r = f - q p (exact, one fma) is an integer in [0, p + 2] <= 255.
+//   Contractions of at most 256 bytes (|s| < 2^22) skip the fold.
+__device__ __forceinline__ float rns_reduce_f(int s, float oldf, float p, float inv_p, int c4096, bool fold) {
+    int t = s;
+    if (fold) t = (s >> 12) * c4096 + (s & 4095);
+    const float f = (float)t + oldf;
+    const float q = floorf(fmaf(f, inv_p, -0.006f));
+    return fmaf(-q, p, f);
 }
 
 
@@ -130,7 +141,6 @@ struct RnsGemm256Args {
     int mt_all, nt_all;
     int mt, c0, c1;        // 256-row tiles 0..mt, 256-column tiles c0..c1
     int K;                 // multiple of 128
-    int kpanel;            // an exact in-register reduction mod p is applied every kpanel bytes of K (<= 896)
     int first;
     int tri;               // 1: only the tiles with ti >= tc (lower block triangle: the Cholesky's trailing update)
     int sr, sc;            // super-tile counts: 8 row tiles x 4 column tiles each
@@ -149,13 +159,23 @@ __device__ __forceinline__ void rns_glds16(const signed char *src, unsigned char
 // Inside a stage the fragments of k step j+1 are read in the MFMA gaps of k step j (one DS read per gap, T19 of the
 // programming guide), and the stage barrier sits before the last k step, so the matrix pipe is busy while the waves
 // synchronise.  Versions measured on the way (C3 candidate solve, ms): 128 x 128 tiles register-staged 37.7 (2 or 4
-// workgroups per CU alike); 256 x 256 register-staged 42.3; LDS-DMA ring of 4 / 5 x 32 KB stages 34.6 / 32.4; this one 31.3.
+// workgroups per CU alike); 256 x 256 register-staged 42.3; LDS-DMA ring of 4 / 5 x 32 KB stages 34.6 / 32.4; this one 31.3
+// (26.9 once one launch contracts 8 panels and reduces mod p once, rns_reduce_f above).
 // Timing ablations of the ring version (wrong results by construction): no MFMA 26.9, no DMA 34.5, no accumulator traffic
 // 32.8, none of the three 17.1 (11 ms of it this kernel's skeleton: barriers, fragment reads, reductions) -- the costs add
 // up instead of overlapping.  Also measured and dropped: the same product as 4-wave workgroups on 128 x 256 tiles, two
 // independent workgroups per CU (33.0 ms), and a row pitch of the L planes off the power of two (no change): neither
-// barrier lockstep nor channel conflicts are the limiter.  All variants sit at 1.5-1.7 Pop/s, the level the programming
-// guide quotes for its simple two-barrier bf16 loop (36 % of peak); its 8-phase schedule is the known way beyond.
+// barrier lockstep nor channel conflicts are the limiter.
+// What IS the limiter (round 2, measured on a ping-pong variant of this kernel -- the programming guide's 8-phase
+// schedule restated for 1-byte operands: 4 x 32 KB ring, the two halves of the workgroup one barrier apart so that one
+// half reads fragments and issues DMA while the other issues MFMAs; same results, same 27 ms -- with its parts switched
+// off; C3 candidate solve, GEMM share of the time): nothing but barriers + epilogue 5 ms, MFMAs only 11 ms (= the
+// 10.9 ms the instruction count needs at 1.95 GHz), fragment reads only 8.6 ms, LDS-DMA ONLY 16.3 ms, all three 20.9 ms.
+// The 174 GB a candidate solve stages from L2 into LDS move at 10.7 TB/s (42 GB/s per CU, between the guide's figures
+// for L2- and Infinity-Cache-served gathers) with nothing else running: a 256 x 256 tile of 1-byte operands needs 1 byte
+// per 256 operations, so the staging path caps this product at ~2.7 Pop/s whatever the schedule (the bare MFMA loop:
+// 3.76 Pop/s, tools/micro/i8_peak.hip), and the kernel runs at 78 % of that cap.  Larger tiles are out of registers
+// (the 256 x 256 int32 accumulators are half of the CU's register file).
 #define R256_STAGE 65536
 __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R256_STAGE];
@@ -192,7 +212,8 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
     }
     unsigned char *la = smem + wave * 32 * 128;
     const int nk = a.K / 128;
-    const int kred = a.kpanel / 128;
+    const bool fold = a.K > 256;   // see rns_reduce_f
+    const int c4096 = 4096 % (int)p;
     auto issue = [&](int kt) {
         unsigned char *sb = la + (kt & 1) * R256_STAGE;
         const long ko = (long)kt * 128;
@@ -277,14 +298,6 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
         mfma_step(1);
         if (next) interleave6();
         __builtin_amdgcn_sched_barrier(0);
-        if ((kt + 1) % kred == 0 && next) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = mod_sym(acc[m][n][r], p, inv_p);
-        }
     }
     int4_t cold[8];
 #pragma unroll
@@ -304,8 +317,9 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
                 unsigned packed = 0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const int s = acc[m][n][w * 4 + b] + (int)(signed char)((unsigned)cold[t][w] >> (8 * b));
-                    packed |= ((unsigned)mod_sym(s, p, inv_p) & 0xffu) << (8 * b);
+                    const float oldf = (float)(((unsigned)cold[t][w] >> (8 * b)) & 0xffu);   // v_cvt_f32_ubyteN
+                    const float r = rns_reduce_f(acc[m][n][w * 4 + b], oldf, p, inv_p, c4096, fold);
+                    packed = __builtin_amdgcn_cvt_pk_u8_f32(r, b, packed);
                 }
                 out[w] = (int)packed;
             }
@@ -315,12 +329,16 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
 }
 
 void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
-                        long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int kpanel,
-                        int first, int tri) {
+                        long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int first,
+                        int tri) {
     if (mt <= 0 || c1 <= c0 || K <= 0) return;
+    if (K > GP_RNS_KMAX || K % 128) {   // callers bound K (api.hip): sums of a longer contraction could leave the exact range
+        fprintf(stderr, "gphip: residue contraction of %d bytes not launched\n", K);
+        return;
+    }
     RnsGemm256Args a;
     a.A = A; a.lda = lda; a.a_plane = a_plane; a.B = B; a.ldb = ldb; a.b_plane = b_plane; a.R = R;
-    a.mt_all = mt_all; a.nt_all = nt_all; a.mt = mt; a.c0 = c0; a.c1 = c1; a.K = K; a.kpanel = kpanel; a.first = first; a.tri = tri;
+    a.mt_all = mt_all; a.nt_all = nt_all; a.mt = mt; a.c0 = c0; a.c1 = c1; a.K = K; a.first = first; a.tri = tri;
     a.sr = (mt + 7) / 8;
     a.sc = (c1 - c0 + 3) / 4;
     const long nwg = (long)RNS_T * a.sr * a.sc * 32;
@@ -370,8 +388,8 @@ __global__ __launch_bounds__(512) void rns_reconstruct256_kernel(const signed ch
             const double ih = c_rns.ih[l], il = c_rns.il[l];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int res = (int)(signed char)((unsigned)v[l][r >> 2] >> (8 * (r & 3)));
-                const float wf0 = (float)(res * q);                 // |r q| < 2^15
+                const int res = (int)(((unsigned)v[l][r >> 2] >> (8 * (r & 3))) & 0xffu);   // any representative in [0, 255]
+                const float wf0 = (float)(res * q);                 // r q < 2^16
                 const float k = rintf(wf0 * inv_p);
                 const double w = (double)fmaf(-k, p, wf0);          // representative of r q mod p, |w| <= p
                 const double t1 = w * ih;

@@ -90,10 +90,36 @@ def test_emulated_equals_fp64_path_on_ragged_shapes(h, N, D, M, pt, variance):
         assert np.max(np.abs(m1b - m1)) <= 1e-9 * max(1.0, np.max(np.abs(m1))) and np.max(np.abs(v1b - v1)) <= 1e-9 * variance
         f1, m2, v2 = h.fit_predict(True)
         assert np.array_equal(m2, m1b) and np.array_equal(v2, v1b)
-        h.set_option("panel_tiles", 8)
-        h.fit()
-        with pytest.raises(ValueError):
-            h.predict(True)
+        # the number of panels one residue launch contracts changes the launches, not the integers they sum
+        for grp in (1, 3):
+            h.set_option("rns_group", grp)
+            m3, v3 = h.predict(True)
+            assert np.array_equal(m3, m1b) and np.array_equal(v3, v1b), grp
+        h.set_option("rns_group", 8)
+    finally:
+        h.set_option("emulate_fp64", 0)
+        h.set_option("panel_tiles", 6)
+        h.set_option("rns_group", 8)
+
+
+def test_emulated_wide_panels(h):
+    """Panels wider than the 896 bytes whose int32 sums an f32 holds exactly: the fold of rns_reduce_f (csrc/rns.hip)
+    brings any sum of a contraction of up to 8192 bytes into range first."""
+    N, D, M = 3072, 4, 500
+    X, Y, Xs = O.synthetic_problem(N, D, M, seed=11)
+    h.set_option("panel_tiles", 8)
+    try:
+        h.set_data(X, Y)
+        h.set_params(0, 0, 1.3, [0.5], 1e-2)
+        h.set_candidates(Xs)
+        f0 = h.fit()
+        m0, v0 = h.predict(True)
+        h.set_option("emulate_fp64", 1)
+        f1 = h.fit()
+        m1, v1 = h.predict(True)
+        assert abs(f1[0] - f0[0]) <= 1e-10 * abs(f0[0])
+        assert np.max(np.abs(m1 - m0)) <= 1e-9 * max(1.0, np.max(np.abs(m0)))
+        assert np.max(np.abs(v1 - v0)) <= 1e-9 * 1.3
     finally:
         h.set_option("emulate_fp64", 0)
         h.set_option("panel_tiles", 6)

@@ -58,7 +58,7 @@ struct gp_ctx {
     int bulk_reserved = -1;        // reserved-CU count s_bulk was created with
     hipStream_t s_inv = nullptr, s_pred = nullptr;  // pipelined candidate solve (gp_fit_predict), low priority
     // stream-ordering events of the look-ahead factorisation, one dense vector per role (EV_* below)
-    std::vector<hipEvent_t> la_events[4];
+    std::vector<hipEvent_t> la_events[6];
     // data
     long N = 0, Npad = 0;
     int D = 0, P = 0;
@@ -157,6 +157,7 @@ struct gp_ctx {
     unsigned *dSync = nullptr;
     int emulate_fp64 = 0;
     int rns_group = 8; // panels per residue launch of the emulated candidate solve
+    int rns_group_fit = 8;  // ... and of the emulated trailing update of the factorisation
     int rns_pad = 0;   // bytes added to the row pitch of L's residue planes (measured: no effect)
     signed char *dLr = nullptr, *dSr = nullptr, *dRr = nullptr;  // residue planes of L, of the current S panel, accumulator
     signed char *dRm = nullptr;                                   // residue accumulator of the trailing matrix (factorisation)
@@ -170,7 +171,8 @@ struct gp_ctx {
 };
 
 static int ensure_bulk_stream(gp_ctx *g);
-enum { EV_CHAIN = 0, EV_BULK = 1, EV_INVP = 2, EV_MISC = 3 };  // chain(J) done, bulk(J) done, invP_J built, fork/join/side
+enum { EV_CHAIN = 0, EV_BULK = 1, EV_INVP = 2, EV_MISC = 3, EV_FAR = 4, EV_CONV = 5 };  // chain(J) done, bulk(J) done, invP_J built,
+                                                                                    // fork/join/side, far launch of group g done, residues of panel J written
 static hipEvent_t la_event(gp_ctx *g, int kind, size_t i);
 
 // One set of HIP streams per device for the whole process, created once in a fixed order and never destroyed.
@@ -574,6 +576,9 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->rns_pad = (int)value;
         g->lr_valid = false;
         if (g->dLr) { hipFree(g->dLr); g->dLr = nullptr; g->capLr = 0; }
+    } else if (!strcmp(name, "rns_group_fit")) {
+        if (value < 1 || value > 16) return fail(GP_ERR_ARG, "rns_group_fit must be in [1, 16]");
+        g->rns_group_fit = (int)value;
     } else if (!strcmp(name, "rns_group")) {
         if (value < 1 || value > 16) return fail(GP_ERR_ARG, "rns_group must be in [1, 16]");
         g->rns_group = (int)value;
@@ -891,8 +896,14 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
         if ((rc = byte_realloc(&g->dRm, &g->capRm, need))) return rc;
         HIPCHK(hipMemsetAsync(rflag, 0, sizeof(int), g->s));
     }
+    // emulated: panels per residue launch (the far launches ride on the otherwise idle candidate stream)
+    const int Gf = (emu && !pp.on) ? std::max(1, std::min(g->rns_group_fit, (int)(GP_RNS_KMAX / PB))) : 1;
+    hipStream_t sfar = g->s_pred;
+    std::vector<char> far_issued(nJ / std::max(1, Gf) + 2, 0);
+    if (Gf > 1) hipStreamWaitEvent(sfar, e0, 0);
     for (int J = 0; J < nJ; ++J) {
         const int J0 = pb[J], J1 = pb[J + 1], J2 = pb[J + 2];
+        bool bulk_recorded = false;
         if (!pp.on && g->tail_tiles > 0 && nt - J0 <= g->tail_tiles) {
             // the trailing columns J0 .. nt-1 in one persistent launch on the chain stream: panel J's columns are
             // complete in stream order (look-ahead update J-1), everything right of them once bulk(J-1) is
@@ -963,16 +974,53 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
             hipStreamWaitEvent(sb, eF, 0);
             if (emu) {
                 rns_convert_panel(g, sb, rg, J, rflag);
-                launch_rns_gemm256(sb, g->dLr + (long)J0 * GP_TILE, rg.Lpitch, rg.Lplane, g->dLr + (long)J0 * GP_TILE, rg.Lpitch,
-                                   rg.Lplane, g->dRm, rg.nt256, rg.nt256, rg.nt256, J2 / 2, rg.nt256, K, J == 0 ? 1 : 0, 1);
                 // the right-hand-side tile row rides in fp64
                 gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
                      TileSet{nt, R1, J2, nt, 0});
+                auto rlaunch = [&](hipStream_t st, int Jfirst, int t0, int t1, int first) {   // panels Jfirst..J -> tiles [t0, t1)
+                    t1 = std::min(t1, nt);
+                    if (t0 >= t1) return;
+                    const int T0 = pb[Jfirst];
+                    launch_rns_gemm256(st, g->dLr + (long)T0 * GP_TILE, rg.Lpitch, rg.Lplane, g->dLr + (long)T0 * GP_TILE, rg.Lpitch,
+                                       rg.Lplane, g->dRm, rg.nt256, rg.nt256, rg.nt256, t0 / 2, (t1 + 1) / 2, (J1 - T0) * GP_TILE,
+                                       first, 1);
+                };
+                auto pbi = [&](int k) { return pb[std::min(k, nJ + 1)]; };
+                if (Gf == 1) {
+                    rlaunch(sb, J, J2, nt, J == 0 ? 1 : 0);
+                } else {
+                    // Panels in groups of Gf (all panel edges sit on 256-column accumulator blocks).  Pair (panel j, column
+                    // panel c >= j+2; c = j+1 is the fp64 look-ahead) is served exactly once, by
+                    //   near(J)  on the bulk stream, every iteration: the group's panels so far -> the columns of panel J+2,
+                    //   mid(g)   on the bulk stream, at the group's last panel: the whole group -> the next Gf column panels,
+                    //   far(g)   on a stream of its own: the whole group -> everything right of that,
+                    // so the accumulator makes one round trip per group for the far columns and the long launch (K = Gf PB)
+                    // overlaps the next group's chain.  Ordering: near(J) and mid(g) accumulate into blocks far(g-1) / far(g-2)
+                    // wrote (mid waits for far(g-1); near follows mid(g-1) in stream order); far(g) follows far(g-1) in stream
+                    // order; the chain's reconstruction of panel J+1's columns waits for bulk(J-1) = near(J-1), recorded
+                    // BEFORE mid so that the chain does not wait for it.  The integers summed are those of Gf = 1.
+                    const int gi = J / Gf, Jg = gi * Gf;
+                    const int first = gi == 0 ? 1 : 0;
+                    hipEventRecord(la_event(g, EV_CONV, J), sb);
+                    rlaunch(sb, Jg, pbi(J + 2), pbi(J + 3), first);
+                    hipEventRecord(la_event(g, EV_BULK, J), sb);
+                    bulk_recorded = true;
+                    if (J % Gf == Gf - 1) {
+                        if (gi >= 1 && far_issued[gi - 1]) hipStreamWaitEvent(sb, la_event(g, EV_FAR, gi - 1), 0);
+                        rlaunch(sb, Jg, pbi(J + 3), pbi(J + 3 + Gf), first);
+                        if (pbi(J + 3 + Gf) < nt) {
+                            hipStreamWaitEvent(sfar, la_event(g, EV_CONV, J), 0);
+                            rlaunch(sfar, Jg, pbi(J + 3 + Gf), nt, first);
+                            hipEventRecord(la_event(g, EV_FAR, gi), sfar);
+                            far_issued[gi] = true;
+                        }
+                    }
+                }
             } else {
                 gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
                      TileSet{0, R1, J2, nt, 1});
             }
-            hipEventRecord(la_event(g, EV_BULK, J), sb);
+            if (!bulk_recorded) hipEventRecord(la_event(g, EV_BULK, J), sb);
         }
     }
     // join
@@ -981,6 +1029,11 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     hipEventRecord(eb, sb);
     hipStreamWaitEvent(g->s, ep, 0);
     hipStreamWaitEvent(g->s, eb, 0);
+    if (Gf > 1) {   // (every far launch ends before the factor is complete: mid of the next group waits for it; join anyway)
+        hipEvent_t ef = la_event(g, EV_MISC, 7);
+        hipEventRecord(ef, sfar);
+        hipStreamWaitEvent(g->s, ef, 0);
+    }
     g->pipe_done = pstages;
     if (pp.on) {
         hipEvent_t eq = la_event(g, EV_MISC, 3), ei = la_event(g, EV_MISC, 4);

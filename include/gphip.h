@@ -252,8 +252,8 @@ int gp_synchronize(gp_t *gp);
  *                        (csrc/rns.hip): operands as 52-bit fixed point, 16 moduli, exact int32 accumulation, CRT
  *                        reconstruction once per column.  Same results to ~1e-12 (only the operands are rounded, to one
  *                        fp64 ulp of the largest entry); gp_fit_predict then runs fit and predict
- *                        one after the other.  "rns_group" (default 8, 1..16): panels per residue launch of the
- *                        candidate solve (the result does not depend on it).
+ *                        one after the other.  "rns_group" / "rns_group_fit" (default 8, 1..16): panels per residue
+ *                        launch of the candidate solve / of the factorisation's trailing update (results do not depend on them).
  *   "profile_min_tiles"  see gp_profile
  * The number of CUs kept free of the trailing update for the look-ahead chain is fixed per process
  * (environment GPHIP_RESERVE_CUS, default 32; "reserve_cus" only checks the value). */

@@ -198,6 +198,32 @@ def test_emulated_trailing_update_of_the_factorisation(h, N, D, pt, noise, P):
         h.set_option("panel_tiles", 6)
 
 
+@pytest.mark.parametrize("N,pt", [(4096, 2), (5000, 2), (6144, 4)])
+def test_emulated_factorisation_does_not_depend_on_the_grouping(h, N, pt):
+    """rns_group_fit panels per residue launch (near / mid / far launches on two streams, csrc/api.hip): the integers
+    summed are the same, so the factor must be BITWISE the one of one launch per panel."""
+    X, Y, Xs = O.synthetic_problem(N, 5, 64, seed=N + pt)
+    h.set_option("panel_tiles", pt)
+    h.set_option("emulate_fp64", 1)
+    try:
+        h.set_data(X, Y)
+        h.set_params(1, 0, 1.1, [0.6], 1e-2)
+        h.set_candidates(Xs)
+        h.set_option("rns_group_fit", 1)
+        f1 = h.fit()
+        L1, a1 = h.chol(), h.alpha()
+        for grp in (2, 3, 4, 8):
+            h.set_option("rns_group_fit", grp)
+            f = h.fit()
+            assert f == f1, grp
+            assert np.array_equal(h.chol(), L1), grp
+            assert np.array_equal(h.alpha(), a1), grp
+    finally:
+        h.set_option("rns_group_fit", 8)
+        h.set_option("emulate_fp64", 0)
+        h.set_option("panel_tiles", 6)
+
+
 def test_emulated_fit_headline_configuration_full_size(h):
     """C3 with the factorisation's trailing update AND the candidate solve emulated: LML 1e-8, alpha / mean / variance
     1e-6 against the independent full-size oracle."""

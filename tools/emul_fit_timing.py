@@ -11,8 +11,9 @@ for kv in sys.argv[1:]:
     k, v = kv.split("="); h.set_option(k, int(v))
 h.set_data(X, Y); h.set_params(0, 0, 1.0, [0.25 * np.sqrt(D)], 1e-2); h.set_candidates(Xs)
 ref = None
-for emu, efit in ((0, 0), (1, 1), (0, 0), (1, 1)):
-    h.set_option("emulate_fp64", emu); h.set_option("emulate_fit", efit)
+for emu, efit in ((0, 0), (1, 1), (1, 2), (1, 4), (1, 8), (0, 0), (1, 4)):
+    h.set_option("emulate_fp64", emu); h.set_option("emulate_fit", 1 if efit else 0)
+    if efit: h.set_option("rns_group_fit", efit)
     h.fit(); h.predict(True)
     h.synchronize(); t0 = time.perf_counter()
     for _ in range(4):
@@ -24,7 +25,7 @@ for emu, efit in ((0, 0), (1, 1), (0, 0), (1, 1)):
         h.fit(); mu, var = h.predict(True); f = h.fmin(); h.acq_argbest(_lib.GP_ACQ_EI, 0.01, f, -1)
     h.synchronize(); ts = (time.perf_counter() - t0) / 4 * 1e3
     if ref is None: ref = (lml, mu.copy(), var.copy())
-    print("emulate_fp64=%d emulate_fit=%d  fit %.2f ms (cholesky %.2f = %.1f TFLOP/s eq)  step(fit+predict+EI) %.2f ms = %.2f it/s   lml rel diff %.1e  var rel diff %.1e"
+    print("emulate_fp64=%d rns_group_fit=%d  fit %.2f ms (cholesky %.2f = %.1f TFLOP/s eq)  step(fit+predict+EI) %.2f ms = %.2f it/s   lml rel diff %.1e  var rel diff %.1e"
           % (emu, efit, tf, phf["cholesky"], N ** 3 / 3.0 / phf["cholesky"] / 1e9, ts, 1e3 / ts, abs(lml - ref[0]) / abs(ref[0]),
              np.max(np.abs(var - ref[2]) / ref[2])))
 h.close()

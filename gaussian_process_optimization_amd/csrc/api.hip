@@ -964,10 +964,8 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
         // the look-ahead update is on the critical path: enqueue it before the trailing update so that its
         // workgroups reach the dispatcher first once bulk(J-1) has drained
         if (J >= 1) hipStreamWaitEvent(sp, la_event(g, EV_BULK, J - 1), 0);
-        // emulated: the look-ahead panel's columns take everything the residue accumulator holds for them (panels
-        // 0 .. J-1) before the fp64 update with panel J
-        if (emu && J >= 1)
-            launch_rns_reconstruct256(sp, g->dRm, rg.nt256, rg.nt256, rg.nt256, J1, J2, Npad_rows(g), A, lda, rg.back, 1);
+        // (emulated: the look-ahead panel's columns took everything the residue accumulator holds for them -- panels
+        // 0 .. J-1 -- on the bulk stream, before bulk(J-1) was recorded)
         gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
              TileSet{0, R1, J1, J2, 1});
         if (J2 < nt) {
@@ -986,8 +984,16 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
                                        first, 1);
                 };
                 auto pbi = [&](int k) { return pb[std::min(k, nJ + 1)]; };
+                // rebuild the columns of panel J+2 in fp64 (Ky minus everything accumulated for them: panels 0 .. J) as soon as
+                // the last residue launch into them is enqueued -- on this stream, off the chain
+                auto rebuild_next = [&]() {
+                    if (pbi(J + 2) < nt)
+                        launch_rns_reconstruct256(sb, g->dRm, rg.nt256, rg.nt256, rg.nt256, pbi(J + 2), std::min(pbi(J + 3), nt),
+                                                  Npad_rows(g), A, lda, rg.back, 1);
+                };
                 if (Gf == 1) {
                     rlaunch(sb, J, J2, nt, J == 0 ? 1 : 0);
+                    rebuild_next();
                 } else {
                     // Panels in groups of Gf (all panel edges sit on 256-column accumulator blocks).  Pair (panel j, column
                     // panel c >= j+2; c = j+1 is the fp64 look-ahead) is served exactly once, by
@@ -1003,6 +1009,7 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
                     const int first = gi == 0 ? 1 : 0;
                     hipEventRecord(la_event(g, EV_CONV, J), sb);
                     rlaunch(sb, Jg, pbi(J + 2), pbi(J + 3), first);
+                    rebuild_next();
                     hipEventRecord(la_event(g, EV_BULK, J), sb);
                     bulk_recorded = true;
                     if (J % Gf == Gf - 1) {

@@ -576,6 +576,8 @@ int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->rns_pad = (int)value;
         g->lr_valid = false;
         if (g->dLr) { hipFree(g->dLr); g->dLr = nullptr; g->capLr = 0; }
+    } else if (!strcmp(name, "rns_interleave")) {
+        rns_set_interleave((int)value);   // process-wide A/B switch of the residue GEMM's workgroup order (default 1)
     } else if (!strcmp(name, "rns_group_fit")) {
         if (value < 1 || value > 16) return fail(GP_ERR_ARG, "rns_group_fit must be in [1, 16]");
         g->rns_group_fit = (int)value;

@@ -143,6 +143,7 @@ void launch_zero_upper_diag(hipStream_t s, double *A, long lda, int nt);
 int rns_init_constants(int device);
 void launch_rns_convert(hipStream_t s, const double *src, long ld, long rows, long cols, signed char *dst,
                         long plane_stride, long ldd, double scale, int *flag);
+void rns_set_interleave(int v);
 void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
                         long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K,
                         int first, int tri = 0);

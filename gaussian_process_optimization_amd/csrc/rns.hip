@@ -144,6 +144,7 @@ struct RnsGemm256Args {
     int first;
     int tri;               // 1: only the tiles with ti >= tc (lower block triangle: the Cholesky's trailing update)
     int sr, sc;            // super-tile counts: 8 row tiles x 4 column tiles each
+    int xcd_interleave;    // 1: the XCDs share a modulus at any time (see the kernel), 0: one contiguous chunk per XCD
 };
 
 __device__ __forceinline__ void rns_glds16(const signed char *src, unsigned char *lds_uniform) {
@@ -176,13 +177,23 @@ __device__ __forceinline__ void rns_glds16(const signed char *src, unsigned char
 // per 256 operations, so the staging path caps this product at ~2.7 Pop/s whatever the schedule (the bare MFMA loop:
 // 3.76 Pop/s, tools/micro/i8_peak.hip), and the kernel runs at 78 % of that cap.  Larger tiles are out of registers
 // (the 256 x 256 int32 accumulators are half of the CU's register file).
+// The staging path is sensitive to WHERE the bytes come from: with the eight XCDs on consecutive super-tiles of one
+// modulus at a time (its planes fit the Infinity Cache) instead of one contiguous chunk of the grid -- two moduli -- per
+// XCD, the candidate solve runs in 26.1 instead of 27.3 ms (option "rns_interleave", default 1).  A row pitch of the S
+// planes off 6144 bytes changes nothing.
 #define R256_STAGE 65536
 __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R256_STAGE];
-    const long nwg = gridDim.x, bid = blockIdx.x;
-    const long wg = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    const int within = (int)(wg & 31);
-    const long st = wg >> 5;
+    // Workgroups b, b+8, b+16, ... run on one XCD, in that order: 32 consecutive ones of an XCD form a super-tile (8 x 4
+    // tiles sharing their operand panels in that XCD's L2), and the super-tiles the eight XCDs work on at the same time are
+    // consecutive ones of the SAME modulus, so that what one XCD's L2 misses another has just brought into the
+    // Infinity Cache (the planes of one modulus fit it; those of eight moduli -- one contiguous chunk per XCD -- do not).
+    const long bid = blockIdx.x;
+    const long q = bid >> 3;
+    const int within = (int)(q & 31);
+    // (rotated by the round number: with 8 row super-tiles an XCD would otherwise see the same row super-tile every round,
+    // and in a triangular launch the XCD with the top rows would have nothing to do)
+    const long st = a.xcd_interleave ? (q >> 5) * 8 + ((bid + (q >> 5)) & 7) : ((bid & 7) * ((long)gridDim.x >> 3) + q) >> 5;
     const int nst = a.sr * a.sc;
     const int l = (int)(st / nst);
     const int sti = (int)(st % nst);
@@ -328,6 +339,9 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
 #undef RBOFF
 }
 
+static int g_rns_interleave = 1;
+void rns_set_interleave(int v) { g_rns_interleave = v ? 1 : 0; }
+
 void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
                         long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int first,
                         int tri) {
@@ -338,7 +352,7 @@ void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_pl
     }
     RnsGemm256Args a;
     a.A = A; a.lda = lda; a.a_plane = a_plane; a.B = B; a.ldb = ldb; a.b_plane = b_plane; a.R = R;
-    a.mt_all = mt_all; a.nt_all = nt_all; a.mt = mt; a.c0 = c0; a.c1 = c1; a.K = K; a.first = first; a.tri = tri;
+    a.mt_all = mt_all; a.nt_all = nt_all; a.mt = mt; a.c0 = c0; a.c1 = c1; a.K = K; a.first = first; a.tri = tri; a.xcd_interleave = g_rns_interleave;
     a.sr = (mt + 7) / 8;
     a.sc = (c1 - c0 + 3) / 4;
     const long nwg = (long)RNS_T * a.sr * a.sc * 32;

@@ -11,16 +11,16 @@ for kv in sys.argv[1:]:
     k, v = kv.split("="); h.set_option(k, int(v))
 h.set_data(X, Y); h.set_params(0, 0, 1.0, [0.25 * np.sqrt(D)], 1e-2); h.set_candidates(Xs)
 h.fit()
-for emu, variant, dbg in ((0, 8, 0), (1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (0, 8, 0), (1, 8, 0)):
+for emu, variant, dbg in ((0, 8, 1), (1, 1, 1), (1, 2, 1), (1, 4, 1), (1, 8, 0), (1, 8, 1), (0, 8, 1), (1, 8, 1)):
     h.set_option("emulate_fp64", emu)
-    h.set_option("rns_group", variant)
+    h.set_option("rns_group", variant); h.set_option("rns_interleave", dbg)
     h.predict(True)
     h.synchronize(); t0 = time.perf_counter()
     for _ in range(3):
         mu, var = h.predict(True)
     h.synchronize(); dt = (time.perf_counter() - t0) / 3 * 1e3
     ph = {p["name"]: round(p["ms"], 3) for p in h.phases()}
-    print("emulate_fp64=%d group %d (%d)  predict %.2f ms  (%.1f TFLOP/s fp64-equivalent)  phases %s" % (emu, variant, dbg, dt, float(N) * N * M / dt / 1e9, ph))
+    print("emulate_fp64=%d group %d interleave %d  predict %.2f ms  (%.1f TFLOP/s fp64-equivalent)  phases %s" % (emu, variant, dbg, dt, float(N) * N * M / dt / 1e9, ph))
     if emu == 0: ref = (mu.copy(), var.copy())
     else: print("   max |mean diff| %.2e   max rel var diff %.2e" % (np.max(np.abs(mu - ref[0])), np.max(np.abs(var - ref[1]) / ref[1])))
 h.close()

@@ -247,13 +247,16 @@ int gp_synchronize(gp_t *gp);
  *   "lauum_panels"       Ky^-1 product accumulated per k-panel (default 1)
  *   "pair_tri"           triangular-K products: column tiles paired for equal contraction length (default 2)
  *   "fmin_direct"        gp_fmin through the N^2 product K(X,X) alpha instead of y - d alpha (default 0)
- *   "emulate_fp64"       0/1 (default 0): PROTOTYPE -- the candidate solve's updates T[:, > J] -= S_J L[> J, J]^T (dtrtrs,
- *                        posterior.py:294; 95 % of gp_predict's flops) run on the int8 matrix cores in residue form
- *                        (csrc/rns.hip): operands as 52-bit fixed point, 16 moduli, exact int32 accumulation, CRT
- *                        reconstruction once per column.  Same results to ~1e-12 (only the operands are rounded, to one
- *                        fp64 ulp of the largest entry); gp_fit_predict then runs fit and predict
- *                        one after the other.  "rns_group" / "rns_group_fit" (default 8, 1..16): panels per residue
- *                        launch of the candidate solve / of the factorisation's trailing update (results do not depend on them).
+ *   "emulate_fp64"       0/1 (default 0; environment GPHIP_EMULATE_FP64 sets the default of new contexts): the candidate
+ *                        solve's updates T[:, > J] -= S_J L[> J, J]^T (dtrtrs, posterior.py:294; 95 % of gp_predict's flops)
+ *                        and, with "emulate_fit" (default 1), the factorisation's trailing update (dsyrk/dgemm inside dpotrf,
+ *                        linalg.py:58) run on the int8 matrix cores in residue form (csrc/rns.hip): operands as 52-bit
+ *                        fixed point, 16 moduli, exact int32 accumulation, CRT reconstruction once per column.  Same results
+ *                        to ~1e-12 (only the operands are rounded, to one fp64 ulp of the largest entry); diagonal tiles,
+ *                        panel solves and all reductions stay true fp64; gp_fit_predict then runs fit and predict one after
+ *                        the other.  "rns_group" / "rns_group_fit" (default 8, 1..16): panels per residue launch of the
+ *                        candidate solve / of the trailing update; "rns_interleave" (default 1, process-wide): the eight
+ *                        XCDs work on one modulus at a time.  Results do not depend on these three.
  *   "profile_min_tiles"  see gp_profile
  * The number of CUs kept free of the trailing update for the look-ahead chain is fixed per process
  * (environment GPHIP_RESERVE_CUS, default 32; "reserve_cus" only checks the value). */

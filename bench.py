@@ -318,7 +318,7 @@ def main():
         phe = {p["name"]: round(p["ms"], 3) for p in h.phases()}
         h.set_option("emulate_fp64", 0)
         emulated = {"label": "NOT the headline: the factorisation's trailing update and the candidate solve's updates emulated on int8 "
-                             "MFMA (exact residue arithmetic, 16 moduli; option emulate_fp64); chain, panel products and all "
+                             "MFMA (exact residue arithmetic, 14 moduli; option emulate_fp64); chain, panel products and all "
                              "reductions in true fp64; entry points gp_fit + gp_predict",
                     "ms_per_step": te * 1e3, "iters_per_s": 1.0 / te, "phases_ms_predict": phe,
                     "same_best_candidate": bool(int(oute[1]) == int(ref_best[0])),

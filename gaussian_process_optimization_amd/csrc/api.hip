@@ -785,7 +785,7 @@ static int byte_realloc(signed char **p, long *cap, long need) {
 // The candidate solve S = T L^-T with the running right-hand side's updates  T[:, > J] -= S_J L[> J, J]^T  carried in
 // residue form on the int8 matrix cores (rns.hip; option "emulate_fp64").  Per panel J: the fp64 columns of T are
 // rebuilt from the exact integer accumulator, S_J = T_J invP_J^T runs in fp64 as before (5 % of the flops), S_J is
-// converted to residues and ONE int8 launch (16 moduli) applies it to every column to the right.
+// converted to residues and ONE int8 launch (14 moduli) applies it to every column to the right.
 // Shared state of the residue paths: fixed-point scale, residue planes of L (zeroed padding), per-panel conversion.
 struct RnsGeom {
     int e = 0;

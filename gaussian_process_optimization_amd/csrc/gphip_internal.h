@@ -138,7 +138,7 @@ void launch_dldk(hipStream_t s, double *out, long ldo, const double *alpha, long
 void launch_zero_upper_diag(hipStream_t s, double *A, long lda, int nt);
 
 // ---- rns.hip: fp64-equivalent contraction on the int8 matrix cores (option "emulate_fp64") -----------------------------
-#define GP_RNS_T 16
+#define GP_RNS_T 14
 #define GP_RNS_KMAX 8192   // longest contraction (bytes) one residue launch may take: see rns_reduce_f in rns.hip
 int rns_init_constants(int device);
 void launch_rns_convert(hipStream_t s, const double *src, long ld, long rows, long cols, signed char *dst,

@@ -4,12 +4,17 @@
 // int8 MFMA (v_mfma_i32_32x32x32_i8) runs at 64x that rate with EXACT int32 accumulation.  Scheme (Ozaki scheme II --
 // integer modular emulation of matrix multiplication -- re-arranged so that the accumulator stays in residue form across
 // all panel updates and is reconstructed once per column; model and constants: tools/rns_model.py):
-//   * operands |x| < 2^e are fixed-point integers v = rint(x 2^(52-e)) (exact in fp64), stored as their symmetric residues
-//     v mod p_l (int8) for 16 pairwise coprime moduli p_l <= 253, P = prod p_l ~ 2^125.1;
+//   * operands are fixed-point integers v = rint(x 2^(52-e)) (exact in fp64) with 2^(e-1) >= sqrt(max diag Ky), stored as
+//     their symmetric residues v mod p_l (int8) for 14 pairwise coprime moduli p_l <= 253, P = prod p_l ~ 2^109.9.
+//     Why 14 are enough: every contraction of the path is a product of two ROWS whose Euclidean norms the factorisation
+//     itself bounds -- sum_k L_ck^2 = Ky_cc (Cholesky) and sum_k S_ik^2 <= k(x*, x*) (the posterior variance is >= 0) -- so by
+//     Cauchy-Schwarz |sum_k a_k b_k| <= max diag Ky <= 2^(2e-2) for ANY contraction length, i.e. the exact integer
+//     |X| <= (2^51 + sqrt(N)/2)^2 ~ 2^102 < P/2 = 2^108.9, seven bits to spare (a bound by entry magnitudes alone,
+//     N 2^104, would need 16 moduli).  An entry beyond 2^(e-1) (which a valid factor cannot have) raises the range flag;
 //   * T[:, c] -= sum_J S_J L[c, J]^T (the running right-hand side of dtrtrs, posterior.py:294) becomes, per modulus, an int8
 //     GEMM whose int32 sums are reduced mod p_l and added to a one-byte residue accumulator R_l -- no rounding anywhere;
 //   * before panel c of T is needed in fp64 (for the product with the inverted diagonal panel) the exact integer
-//     X = sum a b (|X| < N 2^104 < P/2) is recovered from its 16 residues by the CRT in fraction form,
+//     X = sum a b (|X| < P/2, above) is recovered from its 14 residues by the CRT in fraction form,
 //     X / P = centred_frac(sum_l w_l / p_l), w_l = r_l q_l mod p_l, with two fp64 accumulators (terms rounded to
 //     multiples of 2^-44 sum exactly; the remainders carry a double-double reciprocal), and T -= X 2^(2e-104).
 // The only approximation is the fixed-point rounding of the operands: absolute 2^(e-53) per entry, i.e. one fp64 ulp of
@@ -21,7 +26,7 @@
 typedef int int4_t __attribute__((ext_vector_type(4)));
 typedef int int16v_t __attribute__((ext_vector_type(16)));
 
-#define RNS_T 16
+#define RNS_T GP_RNS_T
 // K bytes per stage BKB = 128 or 64; LDS row pitch BKB + 16 bytes (conflict-free ds_read_b128 over the rows of a lane group)
 
 struct RnsConst {
@@ -34,7 +39,7 @@ __constant__ RnsConst c_rns;
 
 // pairwise coprime, all <= 253: a quotient that is off by one near a half-way case still leaves |remainder| <= 127, so the
 // symmetric residues need no fix-up step (0.505 * 253 < 128)
-static const int h_moduli[RNS_T] = {253, 251, 249, 247, 245, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193, 191};
+static const int h_moduli[RNS_T] = {253, 251, 249, 247, 245, 241, 239, 233, 229, 227, 223, 211, 199, 197};
 
 static bool g_rns_const_done[64] = {false};
 int rns_init_constants(int device) {
@@ -74,7 +79,8 @@ int rns_init_constants(int device) {
 
 // ---- fp64 -> residue planes ---------------------------------------------------------------------------------------
 // src: rows x cols (row-major, ld); dst plane l: rows x ldd int8 at dst + l * plane_stride.  scale = 2^(52-e).
-// flag: set to 1 when an entry does not fit (|x| scale >= 2^53): the caller then refuses the emulated path.
+// flag: set to 1 when an entry does not fit (|x| scale > 2^51 (1 + 2^-8), see the header): the caller then refuses the
+// emulated path.
 __global__ __launch_bounds__(256) void rns_convert_kernel(const double *src, long ld, long rows, long cols4, signed char *dst,
                                                           long plane_stride, long ldd, double scale, int *flag) {
     const long c4 = blockIdx.x * 256L + threadIdx.x;  // group of 4 consecutive columns
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(256) void rns_convert_kernel(const double *src, lon
     double v[4] = {rint(a[0] * scale), rint(a[1] * scale), rint(b[0] * scale), rint(b[1] * scale)};
     bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bad |= !(fabs(v[i]) < 0x1p53);
+    for (int i = 0; i < 4; ++i) bad |= !(fabs(v[i]) <= 0x1.01p51);
     if (bad) atomicOr(flag, 1);
 #pragma unroll
     for (int l = 0; l < RNS_T; ++l) {
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void rns_gemm256_kernel(RnsGemm256Args a) {
     const int sti = (int)(st % nst);
     const int ti = (sti % a.sr) * 8 + (within & 7);
     const int tc = a.c0 + (sti / a.sr) * 4 + (within >> 3);
-    if (ti >= a.mt || tc >= a.c1 || (a.tri && ti < tc)) return;
+    if (l >= RNS_T || ti >= a.mt || tc >= a.c1 || (a.tri && ti < tc)) return;   // (the grid is rounded up to 8 super-tiles)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -355,7 +361,7 @@ void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_pl
     a.mt_all = mt_all; a.nt_all = nt_all; a.mt = mt; a.c0 = c0; a.c1 = c1; a.K = K; a.first = first; a.tri = tri; a.xcd_interleave = g_rns_interleave;
     a.sr = (mt + 7) / 8;
     a.sc = (c1 - c0 + 3) / 4;
-    const long nwg = (long)RNS_T * a.sr * a.sc * 32;
+    const long nwg = ((long)RNS_T * a.sr * a.sc + 7) / 8 * 8 * 32;   // whole rounds of eight super-tiles (one per XCD)
     hipLaunchKernelGGL(rns_gemm256_kernel, dim3((unsigned)nwg), dim3(512), 0, s, a);
 }
 
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(512) void rns_reconstruct256_kernel(const signed ch
         const int sub = ((wm * 4 + m) * 8 + wn * 2 + n) * 1024;   // sub-block (rb, cb) = (wm*4 + m, wn*2 + n)
         const long row0 = (long)ti * 256 + wm * 128 + m * 32 + 4 * (lane >> 5);
         if ((long)ti * 256 + wm * 128 + m * 32 >= rows) return;   // wave-uniform
-        // everything this tile needs is requested before any of it is used: the 16 residue vectors and the 16 fp64
+        // everything this tile needs is requested before any of it is used: the 14 residue vectors and the 16 fp64
         // values of T to be updated (one batch of loads instead of 32 dependent round trips)
         int4_t v[RNS_T];
 #pragma unroll

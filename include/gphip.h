@@ -251,7 +251,7 @@ int gp_synchronize(gp_t *gp);
  *                        solve's updates T[:, > J] -= S_J L[> J, J]^T (dtrtrs, posterior.py:294; 95 % of gp_predict's flops)
  *                        and, with "emulate_fit" (default 1), the factorisation's trailing update (dsyrk/dgemm inside dpotrf,
  *                        linalg.py:58) run on the int8 matrix cores in residue form (csrc/rns.hip): operands as 52-bit
- *                        fixed point, 16 moduli, exact int32 accumulation, CRT reconstruction once per column.  Same results
+ *                        fixed point, 14 moduli, exact int32 accumulation, CRT reconstruction once per column.  Same results
  *                        to ~1e-12 (only the operands are rounded, to one fp64 ulp of the largest entry); diagonal tiles,
  *                        panel solves and all reductions stay true fp64; gp_fit_predict then runs fit and predict one after
  *                        the other.  "rns_group" / "rns_group_fit" (default 8, 1..16): panels per residue launch of the

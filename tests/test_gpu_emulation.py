@@ -224,6 +224,40 @@ def test_emulated_factorisation_does_not_depend_on_the_grouping(h, N, pt):
         h.set_option("panel_tiles", 6)
 
 
+def test_emulated_row_products_at_the_bound(h):
+    """The 14 moduli rest on |sum_k a_k b_k| <= max diag Ky for rows of L and of L^-1 k* (csrc/rns.hip).  Here the bound is
+    attained: max diag Ky = 1 exactly (no slack in the power-of-two scale), a long lengthscale makes all rows of L nearly
+    parallel (every accumulated product ~ Ky_rc ~ 1 = 2^102 in integer units), and the candidates include training points
+    themselves (rows of L^-1 k* of norm ~ sqrt(variance))."""
+    N, D, M = 2048, 3, 300
+    X, Y, Xs = O.synthetic_problem(N, D, M, seed=77)
+    Xs[:100] = X[:100]
+    noise = 1e-3
+    variance = 1.0 - noise - 1e-8
+    h.set_option("panel_tiles", 2)
+    try:
+        h.set_data(X, Y)
+        h.set_params(0, 0, variance, [6.0], noise)
+        h.set_candidates(Xs)
+        f0 = h.fit()
+        L0 = h.chol()
+        m0, v0 = h.predict(True)
+        assert float(np.min(np.abs(L0[:, 0]))) > 0.97          # rows nearly parallel to the first column
+        h.set_option("emulate_fp64", 1)
+        f1 = h.fit()
+        L1 = h.chol()
+        m1, v1 = h.predict(True)
+        assert f1[2] == f0[2]
+        # (cond(Ky) ~ 1e6..1e7 here: operand rounding of one ulp is amplified accordingly)
+        assert abs(f1[0] - f0[0]) <= 1e-9 * abs(f0[0])
+        assert np.max(np.abs(L1 - L0)) <= 1e-9
+        assert np.max(np.abs(m1 - m0)) <= 1e-7 * max(1.0, np.max(np.abs(m0)))
+        assert np.max(np.abs(v1 - v0)) <= 1e-8
+    finally:
+        h.set_option("emulate_fp64", 0)
+        h.set_option("panel_tiles", 6)
+
+
 def test_emulated_fit_headline_configuration_full_size(h):
     """C3 with the factorisation's trailing update AND the candidate solve emulated: LML 1e-8, alpha / mean / variance
     1e-6 against the independent full-size oracle."""

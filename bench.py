@@ -309,12 +309,15 @@ def main():
         h.set_option("emulate_fp64", 1)
         ref_best = (out[1], out[2])
         step()
+        h.profile(True)          # HIP events around every launch of the residue GEMM, on its stream
         h.synchronize()
         te0 = time.perf_counter()
         for _ in range(args.steps):
             oute = step()
         h.synchronize()
         te = (time.perf_counter() - te0) / args.steps
+        rs = h.rns_stats()
+        h.profile(False)
         phe = {p["name"]: round(p["ms"], 3) for p in h.phases()}
         h.set_option("emulate_fp64", 0)
         emulated = {"label": "NOT the headline: the factorisation's trailing update and the candidate solve's updates emulated on int8 "
@@ -323,7 +326,16 @@ def main():
                     "ms_per_step": te * 1e3, "iters_per_s": 1.0 / te, "phases_ms_predict": phe,
                     "same_best_candidate": bool(int(oute[1]) == int(ref_best[0])),
                     "best_value_rel_diff": abs(oute[2] - ref_best[1]) / max(abs(ref_best[1]), 1e-300),
-                    "lml_equal": bool(oute[0] == out[0])}
+                    "lml_equal": bool(oute[0] == out[0]),
+                    # the dominant kernel of THIS line, priced like the headline's: int8 operations of the blocks each launch
+                    # computes / summed launch durations (HIP events, live) against the dense int8 MFMA peak; what caps it
+                    # below that peak (operand staging, 2.7 Pop/s; a bare MFMA loop sustains 3.76) is in DESIGN.md section 9
+                    "int8_gemm": {"kernel": "rns_gemm256_kernel (v_mfma_i32_32x32x32_i8, 256 x 256 tiles, 14 moduli)",
+                                  "bound": "mfma", "launches": rs["launches"], "kernel_ms_total": rs["ms"],
+                                  "avg_launch_ms": rs["ms"] / max(rs["launches"], 1),
+                                  "achieved": rs["ops"] / max(rs["ms"], 1e-9) / 1e9, "peak": 5000.0, "unit": "Top/s",
+                                  "frac": rs["ops"] / max(rs["ms"], 1e-9) / 1e9 / 5000.0,
+                                  "ops_per_launch_avg": rs["ops"] / max(rs["launches"], 1)}}
 
     # un-timed: per-phase rates from one gp_fit and one gp_predict run one after the other
     h.fit()

@@ -76,6 +76,7 @@ SIGNATURES = [
                                       c_double_p]),
     ("gp_profile", ctypes.c_int, [_vp, ctypes.c_int]),
     ("gp_gemm_stats", ctypes.c_int, [_vp, c_int64_p, c_double_p, c_double_p]),
+    ("gp_rns_stats", ctypes.c_int, [_vp, c_int64_p, c_double_p, c_double_p]),
     ("gp_gemm_busy", ctypes.c_int, [_vp, c_double_p]),
     ("gp_gemm_trace", ctypes.c_int, [_vp, ctypes.c_int, c_int64_p, c_int_p, c_double_p]),
     ("gp_synchronize", ctypes.c_int, [_vp]),
@@ -366,6 +367,11 @@ class Handle(object):
         check(self.lib, self.lib.gp_gemm_stats(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)),
               "gp_gemm_stats")
         return dict(launches=n.value, ms=ms.value, flops=fl.value)
+
+    def rns_stats(self):
+        n, ms, ops = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        check(self.lib, self.lib.gp_rns_stats(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(ops)), "gp_rns_stats")
+        return dict(launches=n.value, ms=ms.value, ops=ops.value)
 
     def gemm_busy(self):
         b = ctypes.c_double()

@@ -118,6 +118,9 @@ struct gp_ctx {
     int nphases = 0;
     bool profiling = false;
     std::vector<hipEvent_t> gemm_events;
+    std::vector<hipEvent_t> rns_events;   // gp_profile: start / end of every residue GEMM launch (rns_gemm256_kernel)
+    size_t rns_ev_used = 0;
+    double rns_ops = 0.0;                 // int8 multiply-adds x 2 of those launches
     std::vector<long> gemm_tiles;
     std::map<std::array<int, 5>, short *> tile_lists;  // cached L2-friendly tile orders (device)
     int supertile = 8;  // long rectangular / triangular launches walk 8 x 8 super-tiles per XCD (fabric traffic 5.35 -> 3.72 GB per launch, same time)
@@ -356,6 +359,31 @@ static void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const 
     g->gemm_flops_all += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n * ((o.k_tri || o.k_end_tri) ? 0.5 : 1.0);
 }
 
+// residue GEMM launch with the same accounting (gp_profile): events on the launch's own stream, int8 operations of the
+// blocks the launch really computes (a triangular launch skips the blocks above the diagonal)
+static void rns_gemm(gp_ctx *g, hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb,
+                     long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int first, int tri = 0) {
+    if (mt <= 0 || c1 <= c0 || K <= 0) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g->profiling) {
+        if (g->rns_ev_used + 2 > g->rns_events.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            g->rns_events.push_back(a);
+            g->rns_events.push_back(b);
+        }
+        e0 = g->rns_events[g->rns_ev_used++];
+        e1 = g->rns_events[g->rns_ev_used++];
+        long blocks = 0;
+        for (int c = c0; c < c1; ++c) blocks += tri ? std::max(0, mt - c) : mt;
+        g->rns_ops += 2.0 * 65536.0 * (double)K * (double)blocks * GP_RNS_T;
+        hipEventRecord(e0, s);
+    }
+    launch_rns_gemm256(s, A, lda, a_plane, B, ldb, b_plane, R, mt_all, nt_all, mt, c0, c1, K, first, tri);
+    if (e1) hipEventRecord(e1, s);
+}
+
 static inline GemmOpt inplace_opt() {
     GemmOpt o;
     o.inplace = 1;
@@ -469,6 +497,9 @@ static void destroy_ctx_events(gp_ctx *g) {
     g->nphases = 0;
     for (hipEvent_t e : g->gemm_events) hipEventDestroy(e);
     g->gemm_events.clear();
+    for (hipEvent_t e : g->rns_events) hipEventDestroy(e);
+    g->rns_events.clear();
+    g->rns_ev_used = 0;
     g->gemm_ev_used = 0;
     g->gemm_tiles.clear();
     g->gemm_K.clear();
@@ -981,7 +1012,7 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
                     t1 = std::min(t1, nt);
                     if (t0 >= t1) return;
                     const int T0 = pb[Jfirst];
-                    launch_rns_gemm256(st, g->dLr + (long)T0 * GP_TILE, rg.Lpitch, rg.Lplane, g->dLr + (long)T0 * GP_TILE, rg.Lpitch,
+                    rns_gemm(g, st, g->dLr + (long)T0 * GP_TILE, rg.Lpitch, rg.Lplane, g->dLr + (long)T0 * GP_TILE, rg.Lpitch,
                                        rg.Lplane, g->dRm, rg.nt256, rg.nt256, rg.nt256, t0 / 2, (t1 + 1) / 2, (J1 - T0) * GP_TILE,
                                        first, 1);
                 };
@@ -1230,7 +1261,7 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
             const int Ja = J0 + i * W, Jb = std::min(Ja + W, nt);
             if (Ja >= nt) break;
             if (i > 0)   // the group's earlier panels -> this panel's columns (whole 256-column blocks: Ja, Jb are even)
-                launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256,
+                rns_gemm(g, s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256,
                                    mt256, Ja / 2, (Jb + 1) / 2, (Ja - J0) * GP_TILE, first ? 1 : 0);
             if (!first || i > 0) launch_rns_reconstruct256(s, g->dRr, mt256, nt256, mt256, Ja, Jb, Mcpad, T, Npad, back);
             panel_solve(Ja, Jb, J + i);
@@ -1242,7 +1273,7 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
         if (last) break;
         const int Jg = J0 + done * W;   // < nt here
         // the whole group -> every column right of it
-        launch_rns_gemm256(s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256, mt256,
+        rns_gemm(g, s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256, mt256,
                            G == 1 ? Jg / 2 : (Jg + 1) / 2, nt256, (Jg - J0) * GP_TILE, first ? 1 : 0);
         first = false;
         J0 = Jg;
@@ -1782,6 +1813,8 @@ int gp_profile(gp_t *g, int on) {
     g->gemm_launches = 0;
     g->gemm_flops = 0.0;
     g->gemm_flops_all = 0.0;
+    g->rns_ev_used = 0;
+    g->rns_ops = 0.0;
     return 0;
 }
 
@@ -1802,6 +1835,25 @@ int gp_gemm_stats(gp_t *g, int64_t *launches, double *ms, double *flops) {
     if (launches) *launches = g->gemm_launches;
     if (ms) *ms = tot;
     if (flops) *flops = g->gemm_flops;
+    return 0;
+}
+
+// The same for the residue GEMM (rns_gemm256_kernel; option "emulate_fp64"): launches, summed durations and int8
+// operations (2 per multiply-add) since gp_profile(1).
+int gp_rns_stats(gp_t *g, int64_t *launches, double *ms, double *ops) {
+    if (!g) return fail(GP_ERR_ARG, "null gp");
+    if (g->dead) return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one");
+    hipSetDevice(g->device);
+    for (hipStream_t st : {g->s_panel, g->s_bulk, g->s_inv, g->s_pred, g->s})
+        if (st) hipStreamSynchronize(st);
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < g->rns_ev_used; i += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g->rns_events[i], g->rns_events[i + 1]) == hipSuccess) tot += t;
+    }
+    if (launches) *launches = (int64_t)(g->rns_ev_used / 2);
+    if (ms) *ms = tot;
+    if (ops) *ops = g->rns_ops;
     return 0;
 }
 

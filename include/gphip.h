@@ -225,6 +225,9 @@ int gp_last_phases(gp_t *gp, int cap, const char **names, double *ms, double *fl
  * (tracing tools).  Reset by gp_profile(gp, 1). */
 int gp_profile(gp_t *gp, int on);
 int gp_gemm_stats(gp_t *gp, int64_t *launches, double *ms, double *flops);
+/* the same for the residue GEMM of "emulate_fp64" (rns_gemm256_kernel, every launch): launches, summed device time, int8
+ * operations (2 per multiply-add of the blocks a launch computes) */
+int gp_rns_stats(gp_t *gp, int64_t *launches, double *ms, double *ops);
 /* wall time (ms) during which at least one profiled launch was running: the union of their intervals.  Launches of
  * gp_fit_predict overlap, so the SUM of durations above counts shared time twice; flops / busy is the kernel's
  * throughput while it runs. */

@@ -170,6 +170,8 @@ struct gp_ctx {
     int lr_W = 0, lr_e = 0;
     double jitter_try = 0.0;        // jitter of the factorisation attempt in progress (fixes the fixed-point scale)
     int emulate_fit = 1;            // emulate_fp64 also covers the factorisation's trailing update
+    bool emu_off_call = false;      // this call fell back to true fp64 (an operand left the fixed-point range)
+    long emu_fallbacks = 0;         // how often that happened
     bool dead = false;  // gp_shutdown ran: the device's streams are gone, only gp_destroy is still valid
 };
 
@@ -919,7 +921,7 @@ static int factor_lookahead(gp_ctx *g, const PredPipe &pp = PredPipe()) {
     // (rns.hip).  The Schur complement right of the look-ahead panel lives as Ky (untouched, in dA) minus an exact integer
     // accumulator dRm; a panel's columns are rebuilt in fp64 once, right before they become the look-ahead target.  The
     // chain (diagonal tiles, panel solves, in-panel and look-ahead updates) and the right-hand-side tile row stay fp64.
-    const bool emu = g->emulate_fp64 && g->emulate_fit && (PB % 256 == 0) && PB <= GP_RNS_KMAX &&
+    const bool emu = g->emulate_fp64 && g->emulate_fit && !g->emu_off_call && (PB % 256 == 0) && PB <= GP_RNS_KMAX &&
                      !(g->panel_tiles_tail > 0) && !(g->tail_tiles > 0);
     RnsGeom rg;
     int *rflag = g->dInfo + 2;
@@ -1208,6 +1210,7 @@ static void solve_rows(gp_ctx *g, double *T, double *S, int mt, int trapezoid, i
     }
 }
 
+#define GP_ERR_RANGE (-1000)   // internal to this file: an operand of the residue path left the fixed-point range
 static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
     const long Npad = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
@@ -1282,7 +1285,8 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (bad) return fail(GP_ERR_STATE, "emulate_fp64: an operand left the fixed-point range (non-finite or > 2^%d)", e);
+    if (bad) return GP_ERR_RANGE;   // (internal: the caller repeats the solve in true fp64)
+    (void)e;
     return 0;
 }
 
@@ -1352,6 +1356,7 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     const double diag_add = g->noise + 1e-8;  // exact_gaussian_inference.py:56
     const double diag0 = (g->kp.gower ? std::pow(g->kp.variance, g->D) : g->kp.variance) + diag_add;
     g->nphases = 0;
+    g->emu_off_call = false;
     g->fitted = false;
     g->fmin_valid = false;
     g->wi_valid = false;
@@ -1400,10 +1405,17 @@ static int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         HIPCHK(hipStreamSynchronize(g->s));
         if (sync_words[1] != 0)
             return fail(GP_ERR_HIP, "cooperative tail kernel: grid barrier timed out (a workgroup was not resident)");
-        if (g->emulate_fp64 && info == 0) {
+        if (g->emulate_fp64 && !g->emu_off_call && info == 0) {
             int bad = 0;
             HIPCHK(hipMemcpy(&bad, g->dInfo + 2, sizeof(int), hipMemcpyDeviceToHost));
-            if (bad) return fail(GP_ERR_STATE, "emulate_fp64: an entry of L left the fixed-point range");
+            if (bad) {
+                // an entry of L outside the fixed-point range (non-finite data): the same attempt again in true fp64, whose
+                // result is what the reference would return for such data
+                g->emu_off_call = true;
+                ++g->emu_fallbacks;
+                g->nphases = 0;
+                continue;
+            }
         }
         if (info == 0) break;
         // jitter ladder, GPy/GPy/util/linalg.py:62-75
@@ -1611,7 +1623,14 @@ static int run_predict(gp_ctx *g, int include_noise) {
         phase_end(g, ph);
         ph = phase_begin(g, g->emulate_fp64 ? "cand_solve_emulated" : "cand_solve", (double)N * N * mc, 0.0);
         if (g->emulate_fp64) {
-            if ((rc = solve_rows_rns(g, g->dT, g->dT2, (int)(mcpad / GP_TILE)))) return rc;
+            rc = solve_rows_rns(g, g->dT, g->dT2, (int)(mcpad / GP_TILE));
+            if (rc == GP_ERR_RANGE) {   // non-finite candidates / factor: this chunk again in true fp64 (NaNs propagate as in the reference)
+                ++g->emu_fallbacks;
+                launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, g->N, Npad, g->kp);
+                solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), 0);
+            } else if (rc) {
+                return rc;
+            }
         } else {
             solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), 0);
         }

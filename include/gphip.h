@@ -257,7 +257,8 @@ int gp_synchronize(gp_t *gp);
  *                        fixed point, 14 moduli, exact int32 accumulation, CRT reconstruction once per column.  Same results
  *                        to ~1e-12 (only the operands are rounded, to one fp64 ulp of the largest entry); diagonal tiles,
  *                        panel solves and all reductions stay true fp64; gp_fit_predict then runs fit and predict one after
- *                        the other.  "rns_group" / "rns_group_fit" (default 8, 1..16): panels per residue launch of the
+ *                        the other.  Non-finite data cannot be put into fixed point: the call then repeats the step in
+ *                        true fp64 (NaNs propagate as in the reference).  "rns_group" / "rns_group_fit" (default 8, 1..16): panels per residue launch of the
  *                        candidate solve / of the trailing update; "rns_interleave" (default 1, process-wide): the eight
  *                        XCDs work on one modulus at a time.  Results do not depend on these three.
  *   "profile_min_tiles"  see gp_profile

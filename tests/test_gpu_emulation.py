@@ -258,6 +258,31 @@ def test_emulated_row_products_at_the_bound(h):
         h.set_option("panel_tiles", 6)
 
 
+def test_emulated_predict_falls_back_to_fp64_on_non_finite_candidates(h):
+    """A NaN candidate cannot be put into fixed point: the chunk is solved again in true fp64, where the NaN stays in its
+    own row as it does in the reference's dtrtrs (posterior.py:294)."""
+    N, D, M = 1500, 3, 260
+    X, Y, Xs = O.synthetic_problem(N, D, M, seed=5)
+    Xs[17, 1] = np.nan
+    h.set_option("panel_tiles", 2)
+    try:
+        h.set_data(X, Y)
+        h.set_params(1, 0, 1.0, [0.5], 1e-2)
+        h.set_candidates(Xs)
+        h.fit()
+        m0, v0 = h.predict(True)
+        h.set_option("emulate_fp64", 1)
+        h.fit()
+        m1, v1 = h.predict(True)
+        assert np.isnan(m1[17]).all() and np.isnan(v1[17]).all()
+        ok = np.ones(M, bool); ok[17] = False
+        assert np.isfinite(m1[ok]).all() and np.isfinite(v1[ok]).all()
+        assert np.max(np.abs(m1[ok] - m0[ok])) <= 1e-9 and np.max(np.abs(v1[ok] - v0[ok])) <= 1e-9
+    finally:
+        h.set_option("emulate_fp64", 0)
+        h.set_option("panel_tiles", 6)
+
+
 def test_emulated_fit_headline_configuration_full_size(h):
     """C3 with the factorisation's trailing update AND the candidate solve emulated: LML 1e-8, alpha / mean / variance
     1e-6 against the independent full-size oracle."""

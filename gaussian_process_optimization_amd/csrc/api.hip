@@ -164,6 +164,8 @@ struct gp_ctx {
     int rns_pad = 0;   // bytes added to the row pitch of L's residue planes (measured: no effect)
     signed char *dLr = nullptr, *dSr = nullptr, *dRr = nullptr;  // residue planes of L, of the current S panel, accumulator
     signed char *dRm = nullptr;                                   // residue accumulator of the trailing matrix (factorisation)
+    signed char *dWr = nullptr;                                   // residue planes of W = L^-T (emulated Ky^-1)
+    long capWr = 0;
     long capLr = 0, capSr = 0, capRr = 0, capRm = 0;
     bool lr_valid = false;          // dLr belongs to the current factor
     std::vector<char> lr_done;      // ... per panel: rows below the panel's diagonal block converted
@@ -527,7 +529,7 @@ int gp_destroy(gp_t *g) {
     if (g->dInfo) hipFree(g->dInfo);
     if (g->dSync) hipFree(g->dSync);
     if (g->dRedI) hipFree(g->dRedI);
-    for (signed char *p : {g->dLr, g->dSr, g->dRr, g->dRm})
+    for (signed char *p : {g->dLr, g->dSr, g->dRr, g->dRm, g->dWr})
         if (p) hipFree(p);
     for (auto &kv : g->tile_lists) hipFree(kv.second);
     // events recorded on the shared streams go first; the streams themselves belong to the per-device set shared by
@@ -1211,7 +1213,19 @@ static void solve_rows(gp_ctx *g, double *T, double *S, int mt, int trapezoid, i
 }
 
 #define GP_ERR_RANGE (-1000)   // internal to this file: an operand of the residue path left the fixed-point range
-static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
+
+// trapezoid (the solve of the identity, for Ky^-1): row tiles beyond a panel's end are still zero, so every step of panel J
+// covers the row tiles [0, J1) only; the solved panels' residues are KEPT, all side by side in planes of N columns (Wr, for
+// the product W W^T afterwards), and S = L^-T has its own fixed-point scale: its rows have norm sqrt((Ky^-1)_ii) <=
+// 1 / sqrt(noise + 1e-8 + jitter), which takes the place of sqrt(max diag Ky) in the bound of rns.hip.
+struct RnsSolveOpt {
+    bool trapezoid = false;
+    int eS = -1;                 // exponent of S's scale (2^(eS-1) >= the largest row norm of S); < 0: that of L
+    signed char *Wr = nullptr;   // full residue planes of S: Wrows x wpitch bytes per plane, zero beyond the written rows
+    long wpitch = 0, wplane = 0;
+};
+
+static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt, const RnsSolveOpt &opt = RnsSolveOpt()) {
     const long Npad = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
     const int W = g->invp_W;
@@ -1231,7 +1245,8 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
     // accumulator blocks for the launches of one group to touch disjoint blocks: odd panel widths take G = 1.
     int G = std::max(1, std::min(g->rns_group, (int)(GP_RNS_KMAX / PB)));
     if (W % 2) G = 1;
-    const long KS = G * PB;
+    const bool keep = opt.Wr != nullptr;
+    const long KS = keep ? opt.wpitch : G * PB;   // row pitch of the S planes
     auto zalloc = [&](signed char **p, long *cap, long need) -> int {
         if (need <= *cap && *p) return 0;
         int r2 = byte_realloc(p, cap, need);
@@ -1240,45 +1255,66 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
         return 0;
     };
     if (PB > GP_RNS_KMAX) return fail(GP_ERR_ARG, "emulate_fp64: panel_tiles too wide for one residue contraction");
-    if ((rc = zalloc(&g->dSr, &g->capSr, (long)GP_RNS_T * Mc256 * KS))) return rc;
+    if (!keep && (rc = zalloc(&g->dSr, &g->capSr, (long)GP_RNS_T * Mc256 * KS))) return rc;
     if ((rc = zalloc(&g->dRr, &g->capRr, (long)GP_RNS_T * mt256 * nt256 * 65536))) return rc;
     hipStream_t s = g->s;
     int *flag = g->dInfo + 2;
     HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), s));
-    const int e = r.e;
-    const double scale = r.scale, back = r.back;
-    const long Lplane = r.Lplane, Splane = Mc256 * KS;
+    const int eS = opt.eS >= 0 ? opt.eS : r.e;
+    const double scaleS = std::ldexp(1.0, 52 - eS), back = std::ldexp(1.0, eS + r.e);
+    const long Lplane = r.Lplane, Splane = keep ? opt.wplane : Mc256 * KS;
+    signed char *Sr = keep ? opt.Wr : g->dSr;
     for (int J = 0; J < (int)g->lr_done.size(); ++J) rns_convert_panel(g, s, r, J, flag);
+    // trapezoid: a launch's row blocks are those that hold a non-zero row of its S panels; blocks the accumulator has
+    // never seen must read as zero, so it starts zeroed and no launch overwrites ("first")
+    if (opt.trapezoid) HIPCHK(hipMemsetAsync(g->dRr, 0, (size_t)GP_RNS_T * mt256 * nt256 * 65536, s));
+    auto rows_of = [&](int Jend) { return opt.trapezoid ? std::min(mt, Jend) : mt; };   // row tiles (128) of a step
     auto panel_solve = [&](int Ja, int Jb, int Jidx) {   // S[:, Ja..Jb) = T[:, Ja..Jb) invP^T, fp64
         GemmOpt o;
         o.k_end_tri = 1;
         o.b_sub = Ja;
         gemm(g, s, 0, S, Npad, T + (long)Ja * GP_TILE, Npad, g->dInvP + (long)Jidx * PB * PB, PB, 1, (Jb - Ja) * GP_TILE,
-             TileSet{0, mt, Ja, Jb, 0}, o);
+             TileSet{0, rows_of(Jb), Ja, Jb, 0}, o);
     };
-    bool first = true;   // no launch has written the accumulator yet: the first group's launches overwrite their blocks
+    bool first = !opt.trapezoid;   // no launch has written the accumulator yet: the first group's launches overwrite their blocks
     for (int J0 = 0, J = 0; J0 < nt;) {
         int done = 0;    // panels of this group solved and converted; they span tiles [J0, Ja)
         bool last = false;
         for (int i = 0; i < G; ++i) {
             const int Ja = J0 + i * W, Jb = std::min(Ja + W, nt);
             if (Ja >= nt) break;
-            if (i > 0)   // the group's earlier panels -> this panel's columns (whole 256-column blocks: Ja, Jb are even)
-                rns_gemm(g, s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256,
-                                   mt256, Ja / 2, (Jb + 1) / 2, (Ja - J0) * GP_TILE, first ? 1 : 0);
-            if (!first || i > 0) launch_rns_reconstruct256(s, g->dRr, mt256, nt256, mt256, Ja, Jb, Mcpad, T, Npad, back);
+            const int rt = rows_of(Jb), rb = (rt + 1) / 2;                 // rows of this panel's steps: tiles, 256-blocks
+            const long rrows = (long)rt * GP_TILE;
+            // the group's earlier panels -> this panel's columns (whole 256-column blocks: Ja, Jb are even); their S rows
+            // beyond tile Ja are zero, so are the products: the launch stops at the blocks that hold rows < Ja
+            if (i > 0)
+                rns_gemm(g, s, Sr + (keep ? (long)J0 * GP_TILE : 0), KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane,
+                         g->dRr, mt256, nt256, opt.trapezoid ? (std::min(mt, Ja) + 1) / 2 : mt256, Ja / 2, (Jb + 1) / 2,
+                         (Ja - J0) * GP_TILE, first ? 1 : 0);
+            if (opt.trapezoid ? (J0 > 0 || i > 0) : (!first || i > 0))
+                launch_rns_reconstruct256(s, g->dRr, mt256, nt256, opt.trapezoid ? rb : mt256, Ja, Jb,
+                                          opt.trapezoid ? std::min(rrows, Mcpad) : Mcpad, T, Npad, back);
             panel_solve(Ja, Jb, J + i);
             done = i + 1;
             if (Jb >= nt) { last = true; break; }
-            launch_rns_convert(s, S + (long)Ja * GP_TILE, Npad, Mcpad, (Jb - Ja) * GP_TILE, g->dSr + (long)i * PB, Splane, KS, scale,
-                               flag);
+            launch_rns_convert(s, S + (long)Ja * GP_TILE, Npad, opt.trapezoid ? rrows : Mcpad, (Jb - Ja) * GP_TILE,
+                               Sr + (keep ? (long)Ja * GP_TILE : (long)i * PB), Splane, KS, scaleS, flag);
         }
-        if (last) break;
+        if (last) {
+            // the last panel's residues are still wanted by the product W W^T
+            if (keep) {
+                const int Ja = J0 + (done - 1) * W, Jb = std::min(Ja + W, nt);
+                launch_rns_convert(s, S + (long)Ja * GP_TILE, Npad, (long)rows_of(Jb) * GP_TILE, (Jb - Ja) * GP_TILE,
+                                   Sr + (long)Ja * GP_TILE, Splane, KS, scaleS, flag);
+            }
+            break;
+        }
         const int Jg = J0 + done * W;   // < nt here
         // the whole group -> every column right of it
-        rns_gemm(g, s, g->dSr, KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr, mt256, nt256, mt256,
-                           G == 1 ? Jg / 2 : (Jg + 1) / 2, nt256, (Jg - J0) * GP_TILE, first ? 1 : 0);
-        first = false;
+        rns_gemm(g, s, Sr + (keep ? (long)J0 * GP_TILE : 0), KS, Splane, g->dLr + (long)J0 * GP_TILE, r.Lpitch, Lplane, g->dRr,
+                 mt256, nt256, opt.trapezoid ? (std::min(mt, Jg) + 1) / 2 : mt256, G == 1 ? Jg / 2 : (Jg + 1) / 2, nt256,
+                 (Jg - J0) * GP_TILE, first ? 1 : 0);
+        if (!opt.trapezoid) first = false;
         J0 = Jg;
         J += done;
     }
@@ -1286,7 +1322,6 @@ static int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt) {
     HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (bad) return GP_ERR_RANGE;   // (internal: the caller repeats the solve in true fp64)
-    (void)e;
     return 0;
 }
 
@@ -2082,6 +2117,54 @@ static int wi_lauum(gp_ctx *g) {
     return 0;
 }
 
+// Ky^-1 in residue form ("emulate_fp64"): W = L^-T by the emulated solve of the identity (trapezoid; the residues of every
+// solved panel stay in planes of N columns), then Ky^-1 = W W^T as residue launches over groups of k panels -- group
+// [k0, k1) adds to the blocks (i, c), c <= i, whose rows lie above tile k1 -- into a zeroed accumulator, one CRT
+// reconstruction of the lower blocks at the end and the same symmetrisation as the fp64 path.  Bound (rns.hip): the rows
+// of W have norm sqrt((Ky^-1)_ii) <= 1 / sqrt(noise + 1e-8 + jitter) = 2^(eS-1) at most, so both contractions stay below
+// 2^102 in integer units.  Reference: dtrtri + dpotri, GPy/GPy/util/linalg.py:127-145,193-214.
+static int wi_rns(gp_ctx *g) {
+    const long Npad = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    const int W = g->invp_W;
+    hipStream_t s = g->s;
+    int rc;
+    RnsGeom r;
+    if ((rc = rns_prepare(g, g->jitter, &r))) return rc;
+    const int nt256 = r.nt256;
+    const double lam = g->noise + 1e-8 + g->jitter;
+    if (!(lam > 0.0)) return GP_ERR_RANGE;
+    const int eS = std::max(0, 1 + (int)std::ceil(std::log2(1.0 / std::sqrt(lam))));
+    const long wpitch = Npad, wrows = (long)nt256 * 256, wplane = wrows * wpitch;
+    if ((rc = byte_realloc(&g->dWr, &g->capWr, (long)GP_RNS_T * wplane))) return rc;
+    HIPCHK(hipMemsetAsync(g->dWr, 0, (size_t)GP_RNS_T * wplane, s));
+    int ph = phase_begin(g, "potri_solve_emulated", (double)g->N * g->N * g->N / 3.0, 0.0);
+    launch_set_identity(s, g->dT, Npad, Npad);
+    RnsSolveOpt o;
+    o.trapezoid = true;
+    o.eS = eS;
+    o.Wr = g->dWr;
+    o.wpitch = wpitch;
+    o.wplane = wplane;
+    if ((rc = solve_rows_rns(g, g->dT, g->dT2, nt, o))) return rc;
+    phase_end(g, ph);
+    ph = phase_begin(g, "potri_lauum_emulated", (double)g->N * g->N * g->N / 3.0, 0.0);
+    HIPCHK(hipMemsetAsync(g->dRr, 0, (size_t)GP_RNS_T * nt256 * nt256 * 65536, s));
+    const long PB = (long)W * GP_TILE;
+    const int G = std::max(1, std::min(g->rns_group, (int)(GP_RNS_KMAX / PB)));
+    for (int k0 = 0; k0 < nt; k0 += G * W) {
+        const int k1 = std::min(k0 + G * W, nt);
+        const int rb = (k1 + 1) / 2;   // row blocks that hold a non-zero row of these columns of W
+        rns_gemm(g, s, g->dWr + (long)k0 * GP_TILE, wpitch, wplane, g->dWr + (long)k0 * GP_TILE, wpitch, wplane, g->dRr, nt256, nt256,
+                 rb, 0, rb, (k1 - k0) * GP_TILE, 0, 1);
+    }
+    HIPCHK(hipMemsetAsync(g->dWi, 0, sizeof(double) * Npad * Npad, s));
+    launch_rns_reconstruct256(s, g->dRr, nt256, nt256, nt256, 0, nt, Npad, g->dWi, Npad, -std::ldexp(1.0, 2 * eS), 1);
+    launch_symmetrize(s, g->dWi, Npad, Npad);
+    phase_end(g, ph);
+    return 0;
+}
+
 static int ensure_wi(gp_ctx *g) {
     if (g->wi_valid) return 0;
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
@@ -2094,6 +2177,17 @@ static int ensure_wi(gp_ctx *g) {
     if ((rc = dev_realloc(&g->dWi, &g->capWi, Npad * Npad))) return rc;
     double *T = g->dT;
     hipStream_t s = g->s;
+    if (g->emulate_fp64 && g->emulate_fit && g->invp_W % 2 == 0) {
+        rc = wi_rns(g);
+        if (rc == 0) {
+            g->wi_valid = true;
+            g->predicted = false;
+            return 0;
+        }
+        if (rc != GP_ERR_RANGE) return rc;
+        ++g->emu_fallbacks;   // non-finite factor: the true-fp64 path below returns what the reference would
+        g->nphases = 0;
+    }
     int ph = phase_begin(g, "potri_solve", (double)g->N * g->N * g->N / 3.0, 0.0);
     launch_set_identity(s, T, Npad, Npad);
     solve_rows(g, T, g->dT2, nt, 1);  // dT2 = L^-T (block upper triangular)
@@ -2174,7 +2268,9 @@ int gp_fit_grad(gp_t *g, int maxtries, double *lml, double *logdet, double *jitt
                                                "Gower K with Euclidean dK/dr, stationary.py:218-238)");
     HIPCHK(hipSetDevice(g->device));
     const int nt = (int)(g->Npad / GP_TILE);
-    const bool can_pipe = g->lookahead && nt > g->panel_tiles;
+    // emulated: Ky^-1 in residue form after the factorisation (wi_rns) instead of fp64 stages pipelined behind it
+    const bool emu_wi = g->emulate_fp64 && g->emulate_fit && g->panel_tiles % 2 == 0;
+    const bool can_pipe = g->lookahead && nt > g->panel_tiles && !emu_wi;
     int rc;
     if ((rc = fit_impl(g, maxtries, can_pipe ? 2 : 0, 0))) return rc;
     if (lml) *lml = g->lml;

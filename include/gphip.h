@@ -253,7 +253,7 @@ int gp_synchronize(gp_t *gp);
  *   "emulate_fp64"       0/1 (default 0; environment GPHIP_EMULATE_FP64 sets the default of new contexts): the candidate
  *                        solve's updates T[:, > J] -= S_J L[> J, J]^T (dtrtrs, posterior.py:294; 95 % of gp_predict's flops)
  *                        and, with "emulate_fit" (default 1), the factorisation's trailing update (dsyrk/dgemm inside dpotrf,
- *                        linalg.py:58) run on the int8 matrix cores in residue form (csrc/rns.hip): operands as 52-bit
+ *                        linalg.py:58) and Ky^-1 (dtrtri + dpotri, linalg.py:127-145) run on the int8 matrix cores in residue form (csrc/rns.hip): operands as 52-bit
  *                        fixed point, 14 moduli, exact int32 accumulation, CRT reconstruction once per column.  Same results
  *                        to ~1e-12 (only the operands are rounded, to one fp64 ulp of the largest entry); diagonal tiles,
  *                        panel solves and all reductions stay true fp64; gp_fit_predict then runs fit and predict one after

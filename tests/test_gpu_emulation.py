@@ -283,6 +283,45 @@ def test_emulated_predict_falls_back_to_fp64_on_non_finite_candidates(h):
         h.set_option("panel_tiles", 6)
 
 
+@pytest.mark.parametrize("N,D,pt,noise,ard", [(2048, 4, 2, 1e-2, 0), (2560, 6, 4, 1e-2, 1), (3000, 3, 6, 1e-4, 0), (1536, 2, 2, 1e-6, 0)])
+def test_emulated_woodbury_inverse_and_hyper_gradients(h, N, D, pt, noise, ard):
+    """emulate_fp64 also covers Ky^-1 (dtrtri + dpotri, linalg.py:127-145,193-214): the solve of the identity and the product
+    W W^T in residue form, W = L^-T on its own fixed-point scale 2^(eS-1) >= 1 / sqrt(noise + 1e-8).  Ky^-1 and the LML
+    gradients against the true-fp64 device path and, for the well-conditioned cases, Ky Ky^-1 = I through the oracle's Ky."""
+    X, Y, Xs = O.synthetic_problem(N, D, 8, seed=N + pt)
+    ls = (0.3 + 0.1 * np.arange(D)) if ard else [0.35 * np.sqrt(D)]
+    h.set_option("panel_tiles", pt)
+    try:
+        h.set_data(X, Y)
+        h.set_params(0, ard, 1.3, ls, noise)
+        h.fit()
+        W0 = h.woodbury_inv()
+        g0 = h.lml_grad(D if ard else 1)
+        h.set_option("emulate_fp64", 1)
+        h.fit()
+        W1 = h.woodbury_inv()
+        ph = [p["name"] for p in h.phases()]
+        assert any(n.startswith("potri_solve_emulated") for n in ph) and any(n.startswith("potri_lauum_emulated") for n in ph), ph
+        g1 = h.lml_grad(D if ard else 1)
+        fg = h.fit_grad(D if ard else 1)
+        # operand rounding: one ulp of 2^(eS-1) ~ 1/sqrt(noise) per entry of W, 1/noise in Ky^-1
+        tol = 1e-9 if noise >= 1e-4 else 1e-6
+        assert np.max(np.abs(W1 - W0)) <= tol * np.max(np.abs(W0))
+        assert np.allclose(W1, W1.T, rtol=0, atol=0)
+        sc = max(1.0, abs(g0[0]), abs(g0[2]), float(np.max(np.abs(g0[1]))))
+        gt = 1e-8 if noise >= 1e-4 else 1e-5
+        assert abs(g1[0] - g0[0]) <= gt * sc and abs(g1[2] - g0[2]) <= gt * sc and np.max(np.abs(g1[1] - g0[1])) <= gt * sc
+        assert fg[1][0] == g1[0] and fg[1][2] == g1[2] and np.array_equal(fg[1][1], g1[1])    # one call == two calls
+        if noise >= 1e-4:
+            kern = O.RBF(D, 1.3, np.asarray(ls, dtype=float), ARD=bool(ard))
+            Ky = kern.K(X) + (noise + 1e-8) * np.eye(N)
+            R = Ky[:256] @ W1 - np.eye(N)[:256]
+            assert np.max(np.abs(R)) <= 1e-8 / noise * 1e-2
+    finally:
+        h.set_option("emulate_fp64", 0)
+        h.set_option("panel_tiles", 6)
+
+
 def test_emulated_fit_headline_configuration_full_size(h):
     """C3 with the factorisation's trailing update AND the candidate solve emulated: LML 1e-8, alpha / mean / variance
     1e-6 against the independent full-size oracle."""

@@ -40,5 +40,5 @@ def ev():
 ms, r = tm(ev, 3)
 h.fit(); phf = {p["name"]: round(p["ms"], 2) for p in h.phases()}
 h.lml_grad(16); phg = {p["name"]: round(p["ms"], 2) for p in h.phases()}
-print("C5 evaluation (LML + 18 gradients) %.1f ms" % ms, phf, phg, "cholesky %.1f TFLOP/s, potri %.1f TFLOP/s" % (32768.0**3 / 3 / phf["cholesky"] / 1e9, 2 * 32768.0**3 / 3 / (phg["potri_solve"] + phg["potri_lauum"]) / 1e9), flush=True)
+print("C5 evaluation (LML + 18 gradients) %.1f ms" % ms, phf, phg, "cholesky %.1f TFLOP/s, potri %.1f TFLOP/s" % (32768.0**3 / 3 / phf["cholesky"] / 1e9, 2 * 32768.0**3 / 3 / sum(v for k, v in phg.items() if k.startswith("potri")) / 1e9), flush=True)
 h.close()

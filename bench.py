@@ -14,14 +14,20 @@ hyper-parameters fixed.
     SURVEY.md 8e) + posterior + EI over the rank's block + device arg-best + ONE RCCL all-gather of the per-rank
     (best value, global row) pair over xGMI + the lowest-index merge.  Total work is fixed as N grows ("strong" -- of
     the predict/EI part; the fit's share is reported separately and does not scale).  value = whole sharded
-    iterations/s (NOT multiplied by the rank count).  One process per GPU, launched by torch.distributed.run;
-    torch is used for rendezvous / barrier / max-over-ranks only (gloo), the data path is libgphip + its RCCL
-    communicator.  --workload c3|c4 overrides the automatic choice (e.g. C4 on one GPU as the strong-scaling base).
+    iterations/s (NOT multiplied by the rank count).  One process per GPU: either launched by torch.distributed.run
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- called plainly as `python bench.py --gpus N`
+    -- this process becomes a launcher that makes NO HIP / RCCL call itself and starts N fresh rank processes
+    (launch_ranks below; never a re-exec of a process that touched the GPU).  torch is used for rendezvous / barrier /
+    max-over-ranks only (gloo), the data path is libgphip + its RCCL communicator.  The ranks compare their merged
+    winners at the end; a disagreement is exit code 3.  --workload c3|c4 overrides the automatic choice (e.g. C4 on one
+    GPU as the strong-scaling base).
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,6 +57,48 @@ def shard_bounds(M, rank, nranks):
     base, rem = divmod(int(M), int(nranks))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def launch_ranks(n, argv, child_cmd=None, poll_s=0.2, grace_s=20.0):
+    """`python bench.py --gpus N` without a launcher around it: start N rank processes of this script and wait.
+
+    The parent touches neither HIP nor RCCL nor torch (nothing GPU-related is imported before this point), so the
+    children are fresh processes, not re-execs of a process that initialised the GPU.  Each child gets RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR=127.0.0.1 and a free MASTER_PORT -- exactly what torch.distributed.run would hand it, so
+    the rank code below is the same either way.  Rank 0 inherits stdout (its ONE JSON line is the job's output), every
+    rank inherits stderr.  When a rank exits non-zero the others get `grace_s` seconds (they may be about to fail the
+    same way), then are terminated by PID; the launcher returns the first non-zero exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = list(child_cmd) if child_cmd is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GPHIP_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this host driver
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, t_fail = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and rc == 0:
+                rc, t_fail = p.returncode, time.monotonic()
+        if t_fail is not None and time.monotonic() - t_fail > grace_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(poll_s)
+    for p in procs:
+        if p.returncode not in (None, 0) and rc == 0:
+            rc = p.returncode
+    return rc if rc >= 0 else 128 - rc   # a signal's negative code as the shell reports it
 
 
 def cpu_baseline(N, D, M, full=False):
@@ -163,11 +211,15 @@ def main():
                     help="C4, N > 1: skip rank 0's un-timed single-GPU pass over the whole table (the strong-scaling base)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one (no GPU call in this process), one fresh child per rank
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (starts its own ranks) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
     dist = None
     if world > 1:
@@ -295,11 +347,19 @@ def main():
     busy_ms = h.gemm_busy()
     phases_timed = {p["name"]: round(p["ms"], 3) for p in h.phases()}   # of the last call of the last timed step
     h.profile(False)
+    ranks_agree, rank_records = True, None
     if dist is not None:
         import torch
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # every rank merged the same gathered pairs: the winners must be identical (C4; C3 ranks score different tables)
+        rank_records = [None] * world
+        dist.all_gather_object(rank_records, {"rank": rank, "best_row": int(out[1]), "best_value": float(out[2]),
+                                              "lml": float(out[0])})
+        if workload == "c4":
+            ranks_agree = all(r["best_row"] == rank_records[0]["best_row"] and
+                              r["best_value"] == rank_records[0]["best_value"] for r in rank_records)
 
     # second, clearly labelled measurement (NOT the headline): the same C3 step with the candidate solve's updates on the
     # int8 matrix cores in residue form (option "emulate_fp64", csrc/rns.hip; fp64-equivalent results, parity-tested in
@@ -381,6 +441,10 @@ def main():
             scaling, value = "strong", job_rate
         cfg.update({"kernel": kname, "noise": 1e-2, "fit": "replicated on every rank (does not shard, SURVEY.md 8e)",
                     "collective": collective, "rccl_comm_ranks": rccl_ranks, "job_iters_per_s": job_rate,
+                    "launcher": ("bench.py itself (launch_ranks: %d fresh rank processes, no GPU call in the parent)" % world)
+                                if os.environ.get("GPHIP_BENCH_LAUNCHED") else
+                                ("torch.distributed.run" if world > 1 else "single process"),
+                    "ranks_agree_on_winner": ranks_agree if world > 1 else None, "rank_records": rank_records,
                     "lml": out[0], "best_candidate_global_row": int(out[1]), "best_value": float(out[2]),
                     "phases_ms_last_timed_call": phases_timed, "phases_ms": phases,
                     "phases_note": "phases_ms: one gp_fit and one predict pass run one after the other AFTER the timed "
@@ -427,6 +491,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     h.close()
+    if not ranks_agree:
+        sys.stderr.write("rank %d: the ranks disagree on the winner: %s\n" % (rank, rank_records))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -47,6 +47,7 @@ SIGNATURES = [
     ("gp_get_chol", ctypes.c_int, [_vp, c_double_p]),
     ("gp_get_woodbury_inv", ctypes.c_int, [_vp, c_double_p]),
     ("gp_kernel_matrix", ctypes.c_int, [_vp, c_double_p]),
+    ("gp_cross_kernel_matrix", ctypes.c_int, [_vp, c_double_p, ctypes.c_int64, c_double_p]),
     ("gp_lml_grad", ctypes.c_int, [_vp, c_double_p, c_double_p, c_double_p]),
     ("gp_fit_grad", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                    c_double_p]),
@@ -72,6 +73,7 @@ SIGNATURES = [
     ("gp_comm_info", ctypes.c_int, [_vp, c_int_p, c_int_p]),
     ("gp_comm_allgather_best", ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int64, c_double_p, c_int64_p]),
     ("gp_comm_bcast_fit", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("gp_comm_selftest_fit_record", ctypes.c_int, [c_double_p, c_double_p, c_int_p]),
     ("gp_last_phases", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), c_double_p, c_double_p,
                                       c_double_p]),
     ("gp_profile", ctypes.c_int, [_vp, ctypes.c_int]),
@@ -265,6 +267,16 @@ class Handle(object):
     def kernel_matrix(self):
         out = np.empty((self.N, self.N))
         check(self.lib, self.lib.gp_kernel_matrix(self.h, dptr(out)), "gp_kernel_matrix")
+        return out
+
+    def cross_kernel_matrix(self, X2):
+        """kern.K(X, X2): [N, M2] (stationary.py:107-140 with X2 given)."""
+        X2 = as_f64(X2, 2)
+        if X2.shape[1] != self.D:
+            raise ValueError("X2 has %d columns, model has %d" % (X2.shape[1], self.D))
+        out = np.empty((self.N, X2.shape[0]))
+        check(self.lib, self.lib.gp_cross_kernel_matrix(self.h, dptr(X2), X2.shape[0], dptr(out)),
+              "gp_cross_kernel_matrix")
         return out
 
     def lml_grad(self, nls):

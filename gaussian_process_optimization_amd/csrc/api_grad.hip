@@ -1,0 +1,167 @@
+// Hyper-parameter gradients of the LML, predictive gradients, acquisition gradients, dL_dK.
+// Reference: Stationary.update_gradients_full (stationary.py:218-238), GP.predictive_gradients (gp.py:407-454).
+#include "api_internal.h"
+
+int lml_grad_impl(gp_ctx *g, double *dvariance, double *dlengthscale, double *dnoise, bool reset_phases) {
+    if (!g || !dvariance || !dlengthscale || !dnoise) return fail(GP_ERR_ARG, "null argument");
+    GP_DEAD_CHECK(g);
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
+    if (g->kp.gower) return fail(GP_ERR_STATE, "hyper-gradients of the Gower kernel are not replicated (the fork mixes "
+                                               "Gower K with Euclidean dK/dr, stationary.py:218-238)");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if (reset_phases) g->nphases = 0;
+    if ((rc = ensure_wi(g))) return rc;
+    const long Npad = g->Npad;
+    const int nt = (int)(Npad / GP_TILE), D = g->D;
+    const long ntile = (long)nt * (nt + 1) / 2;
+    // per-tile partials live in dT (free after ensure_wi): ntile * NACC doubles << Npad^2
+    double *partial = g->dT;
+    int ph = phase_begin(g, "lml_grad", 0.0, 8.0 * (double)g->N * g->N / 2);
+    std::vector<double> host((size_t)GP_GRAD_NACC * ((D + GP_GRAD_CH - 1) / GP_GRAD_CH));
+    int pass = 0;
+    for (int d0 = 0; d0 < D; d0 += GP_GRAD_CH, ++pass) {
+        launch_lml_grad(g->s, g->dX, g->N, Npad, g->kp, g->ard, d0, g->dAlpha, g->P, g->dWi, Npad, partial,
+                        g->dScal + 64 + pass * GP_GRAD_NACC);
+        if (!g->ard) break;
+    }
+    phase_end(g, ph);
+    const int npass = g->ard ? (D + GP_GRAD_CH - 1) / GP_GRAD_CH : 1;
+    HIPCHK(hipMemcpyAsync(host.data(), g->dScal + 64, sizeof(double) * GP_GRAD_NACC * npass, hipMemcpyDeviceToHost,
+                          g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    (void)ntile;
+    *dvariance = host[0] / g->kp.variance;  // stationary.py:224
+    *dnoise = host[1];                      // gaussian.py:78-79
+    if (g->ard) {
+        for (int d = 0; d < D; ++d)         // -sum tmp (dx_q)^2 / l_q^3, stationary.py:230-235,260-261
+            dlengthscale[d] = -host[(d / GP_GRAD_CH) * GP_GRAD_NACC + 2 + (d % GP_GRAD_CH)] / g->kp.ls[d];
+    } else {
+        dlengthscale[0] = -host[2] / g->kp.ls[0];  // -sum(dL_dr * r) / l, stationary.py:237-238
+    }
+    return 0;
+}
+
+extern "C" int gp_lml_grad(gp_t *g, double *dvariance, double *dlengthscale, double *dnoise) {
+    return lml_grad_impl(g, dvariance, dlengthscale, dnoise, true);
+}
+
+// gp_fit + gp_lml_grad as ONE call (what every L-BFGS evaluation of the hyper-parameter loop asks for:
+// Model.objective_function + objective_function_gradients, core/model.py:96-127).  The first stages of the solve for
+// L^-T ride behind the factorisation's latency-bound tail, like the candidate stages of gp_fit_predict.
+extern "C" int gp_fit_grad(gp_t *g, int maxtries, double *lml, double *logdet, double *jitter_used, double *dvariance,
+                double *dlengthscale, double *dnoise) {
+    if (!g || !dvariance || !dlengthscale || !dnoise) return fail(GP_ERR_ARG, "null argument");
+    GP_DEAD_CHECK(g);
+    if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit_grad");
+    if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
+    if (g->kp.gower) return fail(GP_ERR_STATE, "hyper-gradients of the Gower kernel are not replicated (the fork mixes "
+                                               "Gower K with Euclidean dK/dr, stationary.py:218-238)");
+    HIPCHK(hipSetDevice(g->device));
+    const int nt = (int)(g->Npad / GP_TILE);
+    // emulated: Ky^-1 in residue form after the factorisation (wi_rns) instead of fp64 stages pipelined behind it
+    const bool emu_wi = g->emulate_fp64 && g->emulate_fit && g->panel_tiles % 2 == 0;
+    const bool can_pipe = g->lookahead && nt > g->panel_tiles && !emu_wi;
+    int rc;
+    if ((rc = fit_impl(g, maxtries, can_pipe ? 2 : 0, 0))) return rc;
+    if (lml) *lml = g->lml;
+    if (logdet) *logdet = g->logdet;
+    if (jitter_used) *jitter_used = g->jitter;
+    return lml_grad_impl(g, dvariance, dlengthscale, dnoise, false);
+}
+
+// ---- second candidate-sized buffer (beta = K(Xs,X) Ky^-1, or the full covariance) -----------------
+int ensure_grad_buffers(gp_ctx *g, long elemsBeta, long M) {
+    int rc;
+    if ((rc = dev_realloc(&g->dCov, &g->capCov, elemsBeta))) return rc;
+    const long need = M * (long)g->D * std::max(1, g->P);
+    if (!g->dDm || g->capD < need) {
+        for (double **b : {&g->dDm, &g->dDv, &g->dDacq}) {
+            if (*b) hipFree(*b);
+            *b = nullptr;
+        }
+        HIPCHK(hipMalloc((void **)&g->dDm, sizeof(double) * need));
+        HIPCHK(hipMalloc((void **)&g->dDv, sizeof(double) * need));
+        HIPCHK(hipMalloc((void **)&g->dDacq, sizeof(double) * need));
+        g->capD = need;
+    }
+    return 0;
+}
+
+// predictive gradients of all resident candidates into dDm [M, D, P] and dDv [M, D]
+int run_predict_grad(gp_ctx *g) {
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->kp.gower) return fail(GP_ERR_STATE, "predictive gradients of the Gower kernel are not replicated");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    int rc;
+    if ((rc = ensure_wi(g))) return rc;
+    const long M = g->M, N = g->N, Npad = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    const long mc_max = std::min(g->mc_max, round_up(M, GP_TILE));
+    if ((rc = dev_realloc(&g->dT, &g->capT, std::max(g->capT, mc_max * Npad)))) return rc;
+    if ((rc = ensure_grad_buffers(g, mc_max * Npad, M))) return rc;
+    for (long m0 = 0; m0 < M; m0 += mc_max) {
+        const long mc = std::min(mc_max, M - m0);
+        const long mcpad = round_up(mc, GP_TILE);
+        const int mt = (int)(mcpad / GP_TILE);
+        launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, N, Npad, g->kp);
+        // beta = K(Xs, X) Ky^-1   (gp.py:451-452; Ky^-1 symmetric => rows of Wi serve as the B operand)
+        gemm(g, g->s, 0, g->dCov, Npad, g->dT, Npad, g->dWi, Npad, 1, (int)Npad, TileSet{0, mt, 0, nt, 0});
+        launch_predict_grad(g->s, g->dXs + m0 * g->D, mc, g->dX, N, g->kp, g->dAlpha, Npad, g->P, g->dCov, Npad,
+                            g->dDm + m0 * g->D * g->P, g->dDv + m0 * g->D);
+    }
+    g->predicted = false;  // dT no longer holds the solved candidates
+    return 0;
+}
+
+extern "C" int gp_predict_grad(gp_t *g, double *dmdx, double *dvdx) {
+    if (!g || !dmdx || !dvdx) return fail(GP_ERR_ARG, "null argument");
+    GP_DEAD_CHECK(g);
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = run_predict_grad(g))) return rc;
+    HIPCHK(hipMemcpyAsync(dmdx, g->dDm, sizeof(double) * g->M * g->D * g->P, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipMemcpyAsync(dvdx, g->dDv, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    return 0;
+}
+
+extern "C" int gp_acq_grad(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, double *out, double *dout) {
+    if (!g || !out || !dout) return fail(GP_ERR_ARG, "null argument");
+    GP_DEAD_CHECK(g);
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+    if (g->P != 1) return fail(GP_ERR_ARG, "acquisitions need P == 1");
+    if (type < GP_ACQ_EI || type > GP_ACQ_MPI) return fail(GP_ERR_ARG, "unknown acquisition %d", type);
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = ensure_out(g))) return rc;
+    if ((rc = run_predict_grad(g))) return rc;
+    if ((rc = run_predict(g, 1))) return rc;
+    launch_acq_grad(g->s, type, par, fmin, y_mean, y_std, g->dMean, g->dVar, g->dDm, g->dDv, g->M, g->D, g->dAcq,
+                    g->dDacq);
+    HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipMemcpyAsync(dout, g->dDacq, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    return 0;
+}
+
+// ---- dL_dK = 0.5 (alpha alpha^T - P Ky^-1)  (exact_gaussian_inference.py:70) -------------------------------
+// What grad_dict['dL_dK'] carries into kern.update_gradients_full (gp.py:269) when the reference's own kernel classes
+// consume it on the host.  gp_lml_grad forms the same matrix implicitly inside its fused reduction.
+extern "C" int gp_get_dl_dk(gp_t *g, double *dL_dK) {
+    if (!g || !dL_dK) return fail(GP_ERR_ARG, "null argument");
+    GP_DEAD_CHECK(g);
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = ensure_wi(g))) return rc;  // leaves dT free (Npad x Npad)
+    const long N = g->N, Npad = g->Npad;
+    launch_dldk(g->s, g->dT, Npad, g->dAlpha, Npad, g->P, g->dWi, Npad, N);
+    HIPCHK(hipStreamSynchronize(g->s));
+    HIPCHK(hipMemcpy2D(dL_dK, sizeof(double) * N, g->dT, sizeof(double) * Npad, sizeof(double) * N, N,
+                       hipMemcpyDeviceToHost));
+    g->predicted = false;  // dT was reused
+    return 0;
+}

@@ -149,7 +149,3 @@ void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_pl
                         int first, int tri = 0);
 void launch_rns_reconstruct256(hipStream_t s, const signed char *R, int mt_all, int nt_all, int mt, int c0_128, int c1_128,
                                long rows, double *T, long ldt, double scale_2e, int tri = 0);
-
-// potrf.hip: cooperative tail of the factorisation (one persistent launch for the trailing tile columns t0 .. nt-1)
-void launch_chol_tail(hipStream_t s, double *A, long lda, double *invL, int *info, int t0, int nt, int R1, unsigned *sync,
-                      int G);

@@ -159,7 +159,7 @@ __device__ __forceinline__ double4_t mm16(const double *ap, const double *bp, in
     return acc;
 }
 
-// Factor + invert tile t of A (see the header): the body shared by the stand-alone kernel and the cooperative tail kernel.
+// Factor + invert tile t of A (see the header).
 // T: GP_TILE * TS doubles of LDS, Dinv: 8 * DBLK doubles of LDS.  512 threads.
 __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, double *invL, int *info, double *T, double *Dinv) {
 
@@ -297,12 +297,6 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
 }
 
 
-// out-of-line copy for the cooperative tail kernel (keeps that kernel's register allocation per routine)
-__device__ __attribute__((noinline)) void potrf_tile_call(double *A, long lda, int t, double *invL, int *info, double *T,
-                                                          double *Dinv) {
-    potrf_tile_body(A, lda, t, invL, info, T, Dinv);
-}
-
 __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, int t, double *invL, int *info) {
     __shared__ __attribute__((aligned(16))) double T[GP_TILE * TS];
     __shared__ __attribute__((aligned(16))) double Dinv[8 * DBLK];
@@ -311,197 +305,4 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
 
 void launch_potrf_tile(hipStream_t s, double *A, long lda, int t, double *invL, int *info) {
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), 0, s, A, lda, t, invL, info);
-}
-
-// =====================================================================================================================
-// Cooperative tail of the factorisation: ONE persistent launch factors the trailing tile columns t0 .. nt-1.
-//
-// Why: once the trailing matrix is small (or for small N altogether: C2, N = 4096) the stream version is a chain of
-// ~3 dependent launches per 128 columns -- diagonal tile, panel solve, rank-128 update -- whose kernel boundaries,
-// dispatch gaps and the wait for free CUs cost more than the arithmetic (profiles/r01_fit_panel_timeline.txt: 80-140 us
-// per column against 42 us for the diagonal tile itself).  Here G workgroups (one per CU: the diagonal-tile routine
-// needs 148 KB of LDS) stay resident and walk the columns with three grid barriers per column:
-//   S   every workgroup: its share of the panel solve   L(i,j) = A(i,j) inv(L_jj)^T,  i > j
-//   U1  every workgroup: its share of the next column    A(i,j+1) -= L(i,j) L(j+1,j)^T
-//   PU  workgroup 0: factor + invert tile (j+1,j+1)  ||  the others: A(i,c) -= L(i,j) L(c,j)^T for c >= j+2
-// so the diagonal tile of column j+1 is factored while the rest of column j's update runs (one column of look-ahead).
-// Hand-offs between workgroups happen only at the barriers: agent-scope release before the arrival, agent-scope acquire
-// after the poll (cdna_hip_programming.md, Guideline 16); spins are bounded and a timeout makes every workgroup leave.
-// Same arithmetic per tile as the stream version (same potrf body, same k order in the products).
-// =====================================================================================================================
-#define TBK 16
-#define TLSTR 18
-
-// C (op)= A B^T for one 128 x 128 tile with K = 128; 512 threads = 8 waves as 2 x 4, 64 x 32 per wave.
-// MODE 0: C = A B^T (C may alias A: the tile is stored only after every wave has left the K loop);  MODE 1: C -= A B^T.
-template <int MODE>
-__device__ __attribute__((noinline)) void tile_mm512(double *C, long ldc, const double *A, long lda, const double *B, long ldb,
-                                           double *smem) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int li = lane & 15, lg = lane >> 4;
-    constexpr int SBUF = 256 * TLSTR;
-    const int srow = tid >> 3, sch = (tid & 7) * 2;   // 64 rows per pass, 2 passes per operand
-    const double *ap = A + (long)srow * lda + sch;
-    const double *bp = B + (long)srow * ldb + sch;
-    const int soff = srow * TLSTR + sch;
-    double4_t acc[4][2];
-    double *Cw = C + (long)(wm * 64) * ldc + wn * 32;
-    if (MODE == 1) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[m][n][r] = Cw[(long)(m * 16 + 4 * r + lg) * ldc + n * 16 + li];
-    } else {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    }
-    double2_t ra[2], rb[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) ra[q] = *(const double2_t *)(ap + (long)q * 64 * lda);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) rb[q] = *(const double2_t *)(bp + (long)q * 64 * ldb);
-    __syncthreads();   // the staging area may still be read by the previous product
-#pragma unroll
-    for (int q = 0; q < 2; ++q) *(double2_t *)(smem + soff + q * 64 * TLSTR) = ra[q];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) *(double2_t *)(smem + 128 * TLSTR + soff + q * 64 * TLSTR) = rb[q];
-    __syncthreads();
-    const int aoff = (wm * 64 + li) * TLSTR + lg * 4;
-    const int boff = 128 * TLSTR + (wn * 32 + li) * TLSTR + lg * 4;
-    for (int kt = 0; kt < 128 / TBK; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < 128 / TBK;
-        if (more) {
-            ap += TBK;
-            bp += TBK;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) ra[q] = *(const double2_t *)(ap + (long)q * 64 * lda);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) rb[q] = *(const double2_t *)(bp + (long)q * 64 * ldb);
-        }
-        const double *as = smem + buf * SBUF + aoff;
-        const double *bs = smem + buf * SBUF + boff;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double2_t af[4], bf[2];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = *(const double2_t *)(as + m * 16 * TLSTR + h * 2);
-#pragma unroll
-            for (int n = 0; n < 2; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * TLSTR + h * 2);
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m][e], bf[n][e], acc[m][n], 0, 0, MODE == 1 ? 1 : 0);
-        }
-        if (more) {
-            double *As = smem + (buf ^ 1) * SBUF, *Bs = As + 128 * TLSTR;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) *(double2_t *)(As + soff + q * 64 * TLSTR) = ra[q];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) *(double2_t *)(Bs + soff + q * 64 * TLSTR) = rb[q];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cw[(long)(m * 16 + 4 * r + lg) * ldc + n * 16 + li] = acc[m][n][r];
-}
-
-struct TailArgs {
-    double *A;
-    long lda;
-    double *invL;
-    int *info;
-    int t0, nt, R1;
-    unsigned *sync;  // [0] arrivals (monotonic), [1] abort
-};
-
-#define TAIL_SPIN_LIMIT 20000000u
-
-// Grid barrier.  Every wave drains its stores, one lane releases (agent scope), arrives, polls relaxed, acquires.
-__device__ __forceinline__ bool tail_barrier(unsigned *sync, unsigned target, int *s_ok) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        bool ok = true;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > TAIL_SPIN_LIMIT || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false;
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *s_ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-__global__ __launch_bounds__(512) void chol_tail_kernel(TailArgs a) {
-    __shared__ __attribute__((aligned(16))) double lds[GP_TILE * TS + 8 * DBLK];
-    __shared__ int s_ok;
-    double *T = lds, *Dinv = lds + GP_TILE * TS;
-    const int w = blockIdx.x, G = gridDim.x;
-    unsigned epoch = 0;
-    const long lda = a.lda;
-    auto tile = [&](int i, int c) { return a.A + (long)i * GP_TILE * lda + (long)c * GP_TILE; };
-
-    if (w == 0) potrf_tile_call(a.A, lda, a.t0, a.invL, a.info, T, Dinv);
-    if (!tail_barrier(a.sync, ++epoch * G, &s_ok)) return;
-    for (int j = a.t0; j < a.nt; ++j) {
-        const double *inv = a.invL + (long)j * GP_TILE * GP_TILE;
-        // S: panel solve of column j (rows below the diagonal, incl. the right-hand-side tile row)
-        for (int i = j + 1 + w; i < a.R1; i += G) tile_mm512<0>(tile(i, j), lda, tile(i, j), lda, inv, GP_TILE, lds);
-        if (!tail_barrier(a.sync, ++epoch * G, &s_ok)) return;
-        if (j + 1 >= a.nt) break;
-        // U1: column j+1 takes column j's update first, so that its diagonal tile can be factored
-        for (int i = j + 1 + w; i < a.R1; i += G)
-            tile_mm512<1>(tile(i, j + 1), lda, tile(i, j), lda, tile(j + 1, j), lda, lds);
-        if (!tail_barrier(a.sync, ++epoch * G, &s_ok)) return;
-        // PU: workgroup 0 factors tile (j+1, j+1) while the others apply column j to the columns right of j+1
-        if (w == 0) potrf_tile_call(a.A, lda, j + 1, a.invL, a.info, T, Dinv);
-        if (w > 0 || G == 1) {
-            const int first = (G == 1) ? 0 : w - 1, stride = (G == 1) ? 1 : G - 1;
-            int k = first;
-            for (int c = j + 2; c < a.nt; ++c) {
-                const int cnt = a.R1 - c;   // rows c .. R1-1
-                while (k < cnt) {
-                    const int i = c + k;
-                    tile_mm512<1>(tile(i, c), lda, tile(i, j), lda, tile(c, j), lda, lds);
-                    k += stride;
-                }
-                k -= cnt;
-            }
-        }
-        if (!tail_barrier(a.sync, ++epoch * G, &s_ok)) return;
-    }
-}
-
-// Factor the trailing tile columns t0 .. nt-1 (all updates from the columns left of t0 already applied) in one
-// cooperative launch of G workgroups.  sync: 4 unsigned words (zeroed here); sync[1] != 0 afterwards = barrier timeout.
-void launch_chol_tail(hipStream_t s, double *A, long lda, double *invL, int *info, int t0, int nt, int R1, unsigned *sync,
-                      int G) {
-    TailArgs a;
-    a.A = A; a.lda = lda; a.invL = invL; a.info = info; a.t0 = t0; a.nt = nt; a.R1 = R1; a.sync = sync;
-    hipMemsetAsync(sync, 0, 16, s);
-    hipLaunchKernelGGL(chol_tail_kernel, dim3((unsigned)G), dim3(512), 0, s, a);
 }

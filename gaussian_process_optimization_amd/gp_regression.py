@@ -274,6 +274,21 @@ class GPRegression(Parameterized):
         """gp.py:356-379."""
         return self.predict(Xnew, full_cov, Y_metadata, kern, None, False)
 
+    def predict_quantiles(self, X, quantiles=(2.5, 97.5), Y_metadata=None, kern=None, likelihood=None):
+        """gp.py:384-405: predictive quantiles around the prediction at X, one [Nnew, output_dim] array per quantile.
+        The Gaussian likelihood's ``predictive_quantiles`` (gaussian.py:118-119) is
+        ``norm.ppf(q / 100) * sqrt(var + noise) + mu`` on the raw (noise-free, normalised) posterior; the normaliser's
+        ``inverse_mean`` is then applied to each quantile, exactly as the reference does (gp.py:403-404)."""
+        if likelihood is not None and likelihood is not self.likelihood:
+            raise NotImplementedError("a foreign likelihood is outside the accelerated path")
+        from scipy import stats
+        m, v = self._raw_predict(X, full_cov=False, kern=kern)
+        noise = float(self.likelihood.variance)
+        qs = [stats.norm.ppf(q / 100.) * np.sqrt(v + noise) + m for q in quantiles]
+        if self.normalizer is not None:
+            qs = [self.normalizer.inverse_mean(q) for q in qs]
+        return qs
+
     def predictive_gradients(self, Xnew, kern=None):
         """gp.py:407-454: (dmu_dX [M, D, P], dv_dX [M, D])."""
         Xn = np.asarray(Xnew, dtype=float)
@@ -304,7 +319,11 @@ class GPRegression(Parameterized):
             normals = np.random.standard_normal((P, size, M))
         normals = np.asarray(normals, dtype=float).reshape(P, size, M)
         self._stage(X)
-        m, dev, _ = self._h.posterior_samples(normals.reshape(P * size, M), include_noise=False)
+        # jitter of the M x M factorisation (jitchol's ladder on the posterior covariance: mean(diag) * 1e-6 * 10^k,
+        # linalg.py:62-75; 0 when the first attempt succeeds) is kept for the caller: ``posterior_samples_jitter_``.
+        # An exhausted ladder raises LinAlgError as jitchol does -- there is no host fallback.
+        m, dev, self.posterior_samples_jitter_ = self._h.posterior_samples(normals.reshape(P * size, M), include_noise=False,
+                                                                           maxtries=self.max_jitter_tries)
         dev = dev.reshape(P, size, M)
         if self.normalizer is not None:
             # inverse_mean / inverse_variance (normalizer.py:85-108): deviations scale with std, like sqrt(variance)
@@ -347,7 +366,13 @@ class GPRegression(Parameterized):
         x0 = self.optimizer_array if start is None else np.asarray(start, dtype=float)
         if x0.size == 0:
             return None
-        res = _sopt.fmin_l_bfgs_b(self._obj_grad, x0, maxiter=int(max_iters), maxfun=int(max_iters))
+        # paramz' opt_lbfgsb spells the two stopping tolerances ``bfgs_factor`` (factr) and ``gtol`` (pgtol)
+        extra = {}
+        if kwargs.get("bfgs_factor") is not None:
+            extra["factr"] = float(kwargs["bfgs_factor"])
+        if kwargs.get("gtol") is not None:
+            extra["pgtol"] = float(kwargs["gtol"])
+        res = _sopt.fmin_l_bfgs_b(self._obj_grad, x0, maxiter=int(max_iters), maxfun=int(max_iters), **extra)
         xbest = res[0]
         self.optimizer_array = xbest
         self._ensure_fit()

@@ -47,18 +47,18 @@ class Stationary(Parameterized):
 
     # -- device-backed evaluations (API parity; not used by the fit/predict path) ------
     def K(self, X, X2=None):
-        """kern.K(X[, X2]) -- stationary.py:107-140, evaluated by the K-build kernels."""
+        """kern.K(X[, X2]) -- stationary.py:107-140, evaluated by the K-build kernels (kern.py:119 is the contract:
+        X2 None -> K(X, X) with the diagonal forced to the variance, X2 given -> the [N, M2] cross covariance)."""
         h = _lib.Handle(0)
         try:
             X = _lib.as_f64(X, 2)
+            h.set_data(X, np.zeros((X.shape[0], 1)))
+            h.set_params(self._kernel_id, self.ARD, float(self.variance), self.lengthscale.values, 0.0)
+            if self.Gower and self.space is not None:
+                h.set_gower(*gower_config(self.space, self.input_dim))
             if X2 is None:
-                h.set_data(X, np.zeros((X.shape[0], 1)))
-                h.set_params(self._kernel_id, self.ARD, float(self.variance), self.lengthscale.values, 0.0)
-                if self.Gower and self.space is not None:
-                    h.set_gower(*gower_config(self.space, self.input_dim))
                 return h.kernel_matrix()
-            # cross covariance through the candidate path: K(X2 as candidates, X as data)^T
-            raise NotImplementedError("use GPRegression.predict for cross covariances")
+            return h.cross_kernel_matrix(X2)
         finally:
             h.close()
 

@@ -9,8 +9,9 @@ GPU, reduces a local (best value, global row) pair, and ONE collective -- an all
 16 bytes per rank over xGMI (RCCL inside libgphip, gp_comm_allgather_best) -- lets every rank
 take the global best with NumPy's lowest-index tie rule.
 
-``merge_best`` is the pure host part of that step; the collective itself is pluggable so the
-N > 1 logic is covered by world_size-2 gloo tests on CPU (tests/test_sharded_gloo.py).
+``merge_best`` is the pure host part of that step; the collective itself is pluggable (any object with
+``allgather_best`` / ``allgather_topk``) so the N > 1 logic is covered by world_size-2 gloo tests on CPU
+(tests/test_sharded_gloo.py, whose torch.distributed collective lives under tests/: this package imports no torch).
 """
 import numpy as np
 
@@ -64,40 +65,11 @@ class RcclCollective(object):
         return self.h.comm_allgather_topk(vals, idxs, self.nranks)
 
 
-class TorchCollective(object):
-    """Same exchange over ``torch.distributed`` (gloo on CPU for tests; plumbing only)."""
-
-    def __init__(self, nranks):
-        self.nranks = nranks
-
-    def allgather_best(self, val, idx):
-        import torch
-        import torch.distributed as dist
-        v = torch.tensor([float(val)], dtype=torch.float64)
-        i = torch.tensor([int(idx)], dtype=torch.int64)
-        vs = [torch.zeros(1, dtype=torch.float64) for _ in range(self.nranks)]
-        is_ = [torch.zeros(1, dtype=torch.int64) for _ in range(self.nranks)]
-        dist.all_gather(vs, v)
-        dist.all_gather(is_, i)
-        return np.array([t.item() for t in vs]), np.array([t.item() for t in is_], dtype=np.int64)
-
-    def allgather_topk(self, vals, idxs):
-        import torch
-        import torch.distributed as dist
-        v = torch.tensor(np.asarray(vals, dtype=float))
-        i = torch.tensor(np.asarray(idxs, dtype=np.int64))
-        vs = [torch.zeros_like(v) for _ in range(self.nranks)]
-        is_ = [torch.zeros_like(i) for _ in range(self.nranks)]
-        dist.all_gather(vs, v)
-        dist.all_gather(is_, i)
-        return torch.cat(vs).numpy(), torch.cat(is_).numpy()
-
-
 class ShardedCandidates(object):
     """Scores this rank's block of a candidate table and agrees on the global best.
 
     ``score_local(Xblock, sense) -> (local_idx, value)`` is the device call
-    (``Acquisition*.argbest`` on the HIP path); ``collective`` is one of the classes above.
+    (``Acquisition*.argbest`` on the HIP path); ``collective`` is ``RcclCollective`` above (or a test double with the same two methods).
     """
 
     def __init__(self, rank, nranks, collective):

@@ -97,6 +97,11 @@ int gp_get_chol(gp_t *gp, double *L);
 int gp_get_woodbury_inv(gp_t *gp, double *Wi);
 /* kern.K(X) without noise (stationary.py:107-140), for parity tests of the K-build kernel: K[N,N]. */
 int gp_kernel_matrix(gp_t *gp, double *K);
+/* kern.K(X, X2) -- the cross covariance of the kernel contract (Kern.K, GPy/GPy/kern/src/kern.py:119;
+ * Stationary.K with X2 given, stationary.py:107-140: _unscaled_dist's X2 branch :168-173 has no diagonal fix, the Gower
+ * branch :116-135 likewise takes X2).  X = the training inputs of gp_set_data, X2[M2, D] row-major (caller-owned);
+ * K[N, M2] row-major.  Uses the current kernel parameters; leaves the fit and the resident candidates untouched. */
+int gp_cross_kernel_matrix(gp_t *gp, const double *X2, int64_t M2, double *K);
 
 /* GP.parameters_changed gradient push-down (gp.py:268-269):
  *   dL_dK = 0.5 (alpha alpha^T - P Ky^-1) (exact_gaussian_inference.py:70);
@@ -211,6 +216,11 @@ int gp_comm_allgather_topk(gp_t *gp, int k, const double *vals, const int64_t *i
 /* broadcast of a fitted model from root to all ranks: L, alpha, z, inverse tiles and the host-side scalars of the fit
  * (jitter, LML, log det), so that gp_fmin and gp_get_fit_state agree on every rank. */
 int gp_comm_bcast_fit(gp_t *gp, int root);
+/* Host-only self-test of gp_comm_bcast_fit's receiver side (no device, no communicator): packs the root's record from
+ * root_state = {jitter, lml, logdet}, applies it to a scratch context standing in for a receiving rank with stale
+ * results, and reports the receiver's {jitter, lml, logdet} and {fitted, fmin_valid, wi_valid, invp_valid, lr_valid,
+ * predicted}.  Exists because RCCL with 2 ranks cannot run on a 1-GPU box (tests/test_host_logic.py). */
+int gp_comm_selftest_fit_record(const double *root_state, double *state_out, int *flags_out);
 
 /* ---- measurement ---------------------------------------------------------
  * Phase timings of the last gp_fit / gp_predict measured with HIP events on the
@@ -237,12 +247,10 @@ int gp_gemm_trace(gp_t *gp, int cap, int64_t *tiles, int *K, double *ms);
 int gp_synchronize(gp_t *gp);
 /* Tunables (none changes a result beyond rounding; tests/test_gpu_random_shapes.py sweeps the blocking ones):
  *   "panel_tiles"        outer panel width of the factorisation and of the inverted panels, in 128-tiles (default 6)
- *   "panel_tiles_tail", "tail_rows"   narrower factorisation panels once fewer than tail_rows row tiles remain (off)
  *   "lookahead"          0/1: one panel of look-ahead on separate streams (default 1)
- *   "inner_left_rows"    panels at least this tall update their columns left-looking (off)
  *   "mc_max"             candidate rows per chunk (default 16384)
  *   "small_below", "chain_small_below"   launches with fewer 128-tiles run as 64x64 work units (1400 / 400 on the chain)
- *   "waves8", "stagger", "trsm_waves8", "supertile"   GEMM launch shape
+ *   "waves8", "stagger", "trsm_rows64", "supertile"   GEMM launch shape
  *   "pipe_stages", "pipe_start_pct"   gp_fit_predict: how many candidate stages ride behind the factorisation (0 = automatic:
  *                        14 % of the panels, 3 at N = 16384) and
  *                        after which share of its panels they are released (40)

@@ -477,6 +477,17 @@ class OracleGP(object):
     def predict_noiseless(self, Xnew, full_cov=False):
         return self.predict(Xnew, full_cov, include_likelihood=False)
 
+    def predict_quantiles(self, X, quantiles=(2.5, 97.5)):
+        """gp.py:384-405 with Gaussian.predictive_quantiles (likelihoods/gaussian.py:118-119):
+        ``[norm.ppf(q/100) * sqrt(var + noise) + mu for q in quantiles]`` on the raw posterior (gp.py:398), then the
+        normaliser's inverse_mean on each quantile (gp.py:403-404)."""
+        from scipy import stats
+        m, v = self._raw_predict(X, full_cov=False)
+        qs = [stats.norm.ppf(q / 100.) * np.sqrt(v + self.noise_var) + m for q in quantiles]
+        if self.normalizer is not None:
+            qs = [self.normalizer.inverse_mean(q) for q in qs]
+        return qs
+
     def posterior_covariance_between_points(self, X1, X2):
         """gp.py:714-721 -> Posterior.covariance_between_points, posterior.py:109-128."""
         p = self.posterior
@@ -592,6 +603,48 @@ def acquisition_function(f_acqu, indicator=1.0, cost=1.0):
 # ----------------------------------------------------------------------------
 # Synthetic workloads of SURVEY.md 8(d) (shared by tests and bench.py)
 # ----------------------------------------------------------------------------
+def usable_cpus():
+    """CPUs this process may actually run on: the affinity mask, cut by the cgroup CPU quota (cpu.max / cfs_quota) when
+    there is one.  A GPU box reports 64+ cores through os.cpu_count() while the job's share is 16: BLAS with 64 threads
+    on 16 CPUs oversubscribes (dpotrf at 30 GFLOP/s in BENCH_r02) -- timing legs limit their thread pools to this."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, per = float(f1.read()), float(f2.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    env = os.environ.get("GPHIP_CPU_THREADS")
+    if env:
+        n = max(1, int(env))
+    return n
+
+
+def limit_blas_threads(n=None):
+    """threadpoolctl limit of every BLAS / OpenMP pool to ``n`` (default usable_cpus()); returns (limiter, n).  Keep the
+    returned object alive for as long as the limit should hold."""
+    n = int(n or usable_cpus())
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=n), n
+    except Exception:  # noqa: BLE001
+        return None, n
+
+
 def synthetic_problem(N, D, M, seed=1234, standardize=True):
     rng = np.random.default_rng(seed)
     X = rng.uniform(0, 1, (N, D))

@@ -1,0 +1,70 @@
+"""CPU: `python bench.py --gpus N` starts its own rank processes (launch_ranks) -- environment handed to the ranks, exit
+codes, and that the launching process itself touches neither the HIP library nor torch."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_launcher(tmp_path, child_src, n=3):
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent(child_src))
+    code = textwrap.dedent("""
+        import sys, json
+        sys.path.insert(0, %r)
+        import bench
+        rc = bench.launch_ranks(%d, ["--gpus", "%d"], child_cmd=[sys.executable, %r, %r], grace_s=2.0)
+        # the launcher made no GPU call: neither the ctypes binding nor torch was imported by it
+        bad = [m for m in sys.modules if m == "torch" or m.endswith("._lib") or m.startswith("gaussian_process_optimization_amd")]
+        print(json.dumps({"rc": rc, "gpu_modules": bad}))
+    """ % (ROOT, n, n, str(child), str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1]), out.stdout
+
+
+def test_launcher_hands_every_rank_its_environment(tmp_path):
+    res, stdout = _run_launcher(tmp_path, """
+        import json, os, sys
+        keys = ["RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"]
+        rec = {k: os.environ.get(k) for k in keys}
+        open(os.path.join(sys.argv[1], "rank%s.json" % rec["RANK"]), "w").write(json.dumps(rec))
+        print("line from rank " + rec["RANK"])
+    """)
+    assert res == {"rc": 0, "gpu_modules": []}
+    recs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(3)]
+    assert [r["RANK"] for r in recs] == ["0", "1", "2"] and [r["LOCAL_RANK"] for r in recs] == ["0", "1", "2"]
+    assert {r["WORLD_SIZE"] for r in recs} == {"3"} and {r["MASTER_ADDR"] for r in recs} == {"127.0.0.1"}
+    assert len({r["MASTER_PORT"] for r in recs}) == 1 and int(recs[0]["MASTER_PORT"]) > 0
+    assert {r["HSA_ENABLE_IPC_MODE_LEGACY"] for r in recs} == {"0"}
+    # only rank 0 owns stdout: the job prints ONE line
+    assert "line from rank 0" in stdout and "line from rank 1" not in stdout and "line from rank 2" not in stdout
+
+
+def test_launcher_returns_a_failing_ranks_code_and_stops_the_others(tmp_path):
+    res, _ = _run_launcher(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(3)          # e.g. the ranks disagree on the winner
+        time.sleep(60)           # the others would wait at a barrier
+    """)
+    assert res["rc"] == 3
+
+
+def test_plain_invocation_with_gpus_gt_1_becomes_the_launcher():
+    """`python bench.py --gpus 2` without WORLD_SIZE must not demand a launcher any more: main() hands over to launch_ranks
+    before anything GPU-related is imported (here the ranks fail at once -- no GPU in this container -- and the launcher
+    reports that as a non-zero exit instead of raising SystemExit with usage text)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--M", "256", "--N", "256"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    from gaussian_process_optimization_amd import _lib
+    import ctypes
+    n = ctypes.c_int(0)
+    have_gpu = _lib.load_library().gp_device_count(ctypes.byref(n)) == 0 and n.value > 0
+    assert "launch N>1 with" not in out.stderr
+    if not have_gpu:
+        assert out.returncode != 0 and "no HIP device visible" in out.stderr

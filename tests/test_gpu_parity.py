@@ -9,7 +9,7 @@ extended-precision truth (tests/golden/gp_truth.npz) instead of against each oth
 import numpy as np
 import pytest
 
-from conftest import Case, golden_tags, relmax
+from conftest import Case, golden_tags, relmax, emulation_modes
 from gaussian_process_optimization_amd import _lib
 from oracle import cpu_ref as O
 
@@ -22,11 +22,22 @@ def _tags():
     return golden_tags(g)
 
 
-@pytest.fixture(scope="module")
-def h():
+@pytest.fixture(scope="module", params=emulation_modes())
+def h(request):
+    """One context per arithmetic mode: every test of this module runs in true fp64 AND with the bulk contractions
+    emulated on the int8 matrix cores (same tolerances).  Contexts a test creates itself inherit the mode through the
+    environment default (gp_create reads GPHIP_EMULATE_FP64)."""
+    import os
+    prev = os.environ.get("GPHIP_EMULATE_FP64")
+    os.environ["GPHIP_EMULATE_FP64"] = str(request.param)
     hd = _lib.Handle(0)
+    hd.set_option("emulate_fp64", request.param)
     yield hd
     hd.close()
+    if prev is None:
+        os.environ.pop("GPHIP_EMULATE_FP64", None)
+    else:
+        os.environ["GPHIP_EMULATE_FP64"] = prev
 
 
 @pytest.mark.parametrize("tag", _tags())

@@ -142,8 +142,9 @@ def test_posterior_samples_jitter_ladder_on_a_singular_covariance(h):
     _, cov = h.predict_full_cov(False)
     C = dev.T
     assert np.max(np.abs(C @ C.T - cov - jit * np.eye(40))) <= 1e-10 * np.max(np.abs(cov))
-    # the ladder's first rung is mean(diag) * 1e-6 with the prior variance as the diagonal bound
-    assert jit in [1.0 * 1e-6 * 10 ** k for k in range(6)] or jit == pytest.approx(1e-6, rel=1e-9) or jit > 1e-6
+    # the ladder is jitchol's: mean(diag of the matrix being factored) * 1e-6 * 10^k (linalg.py:62-75)
+    base = float(np.mean(np.diag(cov))) * 1e-6
+    assert any(jit == pytest.approx(base * 10 ** k, rel=1e-6) for k in range(6)), (jit, base)
 
 
 def test_posterior_samples_f_host_mirror():

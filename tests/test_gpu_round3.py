@@ -1,0 +1,161 @@
+"""GPU: round-3 additions -- the kernel contract's cross covariance, predictive quantiles, and a deterministic check of the
+hyper-parameter loop (same x0, same scipy L-BFGS-B, device objective vs oracle objective)."""
+import numpy as np
+import pytest
+from scipy import optimize as sopt
+
+import gaussian_process_optimization_amd as gpo
+from conftest import emulation_modes
+from gaussian_process_optimization_amd import _lib
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kname,ard", [("rbf", 0), ("rbf", 1), ("mat52", 0), ("mat52", 1)])
+@pytest.mark.parametrize("N,D,M2", [(300, 3, 77), (129, 8, 256), (64, 1, 1)])
+def test_cross_kernel_matrix_matches_oracle(kname, ard, N, D, M2):
+    """kern.K(X, X2) (Kern.K, kern.py:119; Stationary.K with X2 given, stationary.py:107-140; _unscaled_dist's X2 branch
+    :168-173): [N, M2], no diagonal fix, 1e-13 of the variance against the oracle's restatement -- through the C entry
+    point and through the host mirror's kern.K."""
+    rng = np.random.default_rng(N + D + M2 + ard)
+    X = rng.uniform(0, 1, (N, D))
+    X2 = rng.uniform(-0.2, 1.2, (M2, D))
+    X2[0] = X[min(5, N - 1)]                       # a coincident pair: r = 0 exactly, no special-casing off the diagonal
+    var = 1.7
+    ls = (0.3 + 0.1 * np.arange(D)) if ard else np.array([0.45])
+    kern0 = (O.RBF if kname == "rbf" else O.Matern52)(D, var, ls, ARD=bool(ard))
+    K0 = kern0.K(X, X2)
+    h = _lib.Handle(0)
+    h.set_data(X, np.zeros((N, 1)))
+    h.set_params(0 if kname == "rbf" else 1, ard, var, ls, 0.1)
+    K = h.cross_kernel_matrix(X2)
+    assert K.shape == (N, M2)
+    assert np.max(np.abs(K - K0)) <= 1e-13 * var
+    assert abs(K[min(5, N - 1), 0] - var) <= 1e-15 * var
+    # a fit / resident candidates are left untouched by the call
+    Y = np.sin(X.sum(1, keepdims=True))
+    h.set_data(X, Y)
+    h.set_params(0 if kname == "rbf" else 1, ard, var, ls, 0.1)
+    lml = h.fit()[0]
+    h.set_candidates(X2)
+    mu, v = h.predict(True)
+    K2 = h.cross_kernel_matrix(X[:17])
+    assert np.max(np.abs(K2 - kern0.K(X, X[:17]))) <= 1e-13 * var
+    mu2, v2 = h.predict(True)
+    assert h.fit_state()[0] == lml and np.array_equal(mu, mu2) and np.array_equal(v, v2)
+    h.close()
+    k = (gpo.kern.RBF if kname == "rbf" else gpo.kern.Matern52)(D, var, ls, ARD=bool(ard))
+    assert np.max(np.abs(k.K(X, X2) - K0)) <= 1e-13 * var
+    with pytest.raises(ValueError):
+        k.K(X, np.zeros((3, D + 1)))
+
+
+def test_cross_kernel_matrix_gower_branch():
+    """The fork's Gower branch takes X2 as well (stationary.py:116-135)."""
+    rng = np.random.default_rng(3)
+    N, M2 = 150, 40
+    X = np.c_[rng.uniform(0, 4, (N, 2)), rng.integers(0, 3, (N, 1)).astype(float)]
+    X2 = np.c_[rng.uniform(0, 4, (M2, 2)), rng.integers(0, 3, (M2, 1)).astype(float)]
+    space = gpo.Design_space([{"name": "a", "type": "continuous", "domain": (0, 4)},
+                              {"name": "b", "type": "continuous", "domain": (0, 4)},
+                              {"name": "c", "type": "discrete", "domain": (0, 1, 2)}])
+    for cls, name in ((gpo.kern.Matern52, "Mat52"), (gpo.kern.RBF, "rbf")):
+        k = cls(3, variance=1.3, Gower=True, space=space)
+        k0 = O.make_kernel(name, 3, 1.3, None, Gower=True, space=space)
+        X2[0] = X[3]
+        K, K0 = k.K(X, X2), k0.K(X, X2)
+        assert K.shape == (N, M2)
+        np.testing.assert_allclose(K, K0, rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("normalizer", [False, True])
+def test_predict_quantiles_matches_oracle(normalizer):
+    """GP.predict_quantiles (gp.py:384-405) with Gaussian.predictive_quantiles (gaussian.py:118-119)."""
+    rng = np.random.default_rng(11)
+    X = rng.uniform(0, 1, (200, 2))
+    Y = np.c_[np.sin(5 * X[:, 0]) + 4.0, 3 * np.cos(4 * X[:, 1])] + 0.1 * rng.standard_normal((200, 2))
+    Xs = rng.uniform(0, 1, (57, 2))
+    m = gpo.models.GPRegression(X, Y, gpo.kern.RBF(2, 1.4, 0.3), noise_var=0.02, normalizer=normalizer)
+    gp = O.OracleGP(X, Y, O.RBF(2, 1.4, 0.3), 0.02, normalizer=normalizer)
+    qs = (2.5, 50.0, 97.5, 99.9)
+    got = m.predict_quantiles(Xs, quantiles=qs)
+    ref = gp.predict_quantiles(Xs, quantiles=qs)
+    assert len(got) == len(qs)
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape == (57, 2)
+        assert np.max(np.abs(g - r)) <= 1e-6 * np.max(np.abs(r))
+    # the default pair brackets the predictive mean symmetrically (in the normalised space; inverse_mean is affine)
+    lo, hi = m.predict_quantiles(Xs)
+    mu, _ = m.predict(Xs)
+    assert np.max(np.abs(0.5 * (lo + hi) - mu)) <= 1e-9 * np.max(np.abs(mu))
+    assert (hi > lo).all()
+    m.close()
+
+
+# ---- f3: the hyper-parameter loop, deterministically -------------------------------------------------------------------
+_LIM = 36.0
+
+
+def _logexp(x):        # the positive transform of the parameters (paramz Logexp; restated from its published definition)
+    x = np.asarray(x, dtype=float)
+    return np.where(x > _LIM, x, np.log1p(np.exp(np.clip(x, -700.0, _LIM))))
+
+
+def _logexp_gradfactor(f):
+    f = np.asarray(f, dtype=float)
+    return np.where(f > _LIM, 1.0, -np.expm1(-f))
+
+
+def _oracle_objective(X, Y, kname, ard, D):
+    """-LML and its gradient in the optimiser (Logexp) space from the ORACLE's LML and natural gradients
+    (Model.objective_function / objective_function_gradients, core/model.py:96-127; parameter order of
+    GPRegression: kern.variance, kern.lengthscale[1 or D], Gaussian_noise.variance)."""
+    nls = D if ard else 1
+
+    def fg(x):
+        p = _logexp(x)
+        kern = (O.RBF if kname == "rbf" else O.Matern52)(D, float(p[0]), p[1:1 + nls].copy(), ARD=bool(ard))
+        gp = O.OracleGP(X, Y, kern, float(p[1 + nls]))
+        dv, dl, dn = gp.gradients()
+        g_nat = np.r_[dv, np.atleast_1d(dl), dn]
+        return -gp.log_likelihood(), -(g_nat * _logexp_gradfactor(p))
+    return fg
+
+
+@pytest.mark.parametrize("mode", emulation_modes())
+@pytest.mark.parametrize("kname,ard,N,D", [("rbf", 0, 200, 2), ("mat52", 1, 180, 3)])
+def test_optimize_same_x0_same_lbfgs_matches_oracle_objective(monkeypatch, mode, kname, ard, N, D):
+    """f3 (GPModel.updateModel -> optimize, gpmodel.py:88-93; GP.optimize, gp.py:643-664): from the SAME x0, the SAME
+    scipy.optimize.fmin_l_bfgs_b drives (a) the device objective through GPRegression.optimize and (b) the oracle
+    objective.  The objective / gradient agree at x0 to 1e-9, and the two runs end at the same parameters and LML within
+    1e-6 -- a wrong chain-rule factor that still ascends would end elsewhere."""
+    monkeypatch.setenv("GPHIP_EMULATE_FP64", str(mode))
+    rng = np.random.default_rng(5 + N)
+    X = rng.uniform(0, 1, (N, D))
+    Y = (np.sin(3 * X).sum(1, keepdims=True) + 0.1 * rng.standard_normal((N, 1)))
+    Y = (Y - Y.mean()) / Y.std()
+    kcls = gpo.kern.RBF if kname == "rbf" else gpo.kern.Matern52
+    m = gpo.models.GPRegression(X, Y, kcls(D, 1.0, np.full(D if ard else 1, 0.5), ARD=bool(ard)), noise_var=0.1)
+    x0 = m.optimizer_array.copy()
+    fg = _oracle_objective(X, Y, kname, ard, D)
+    # the transform pair used here is the one the model uses
+    assert np.max(np.abs(_logexp(x0) - np.r_[1.0, np.full(D if ard else 1, 0.5), 0.1])) <= 1e-12
+    f_dev, g_dev = m._obj_grad(x0)
+    f_or, g_or = fg(x0)
+    assert abs(f_dev - f_or) <= 1e-9 * abs(f_or)
+    assert np.max(np.abs(g_dev - g_or)) <= 1e-8 * np.max(np.abs(g_or))
+    tight = dict(maxiter=200, maxfun=200, factr=10.0, pgtol=1e-9)
+    x_or, f_or_end, info_or = sopt.fmin_l_bfgs_b(fg, x0, **tight)
+    m.optimize(start=x0, max_iters=200, bfgs_factor=10.0, gtol=1e-9)
+    x_dev = m.optimizer_array.copy()
+    p_dev, p_or = _logexp(x_dev), _logexp(x_or)
+    assert np.max(np.abs(p_dev - p_or) / np.abs(p_or)) <= 1e-6, (p_dev, p_or, info_or["nit"])
+    assert abs(m.log_likelihood() + f_or_end) <= 1e-6 * abs(f_or_end)
+    assert -f_or_end > -f_or + 1.0          # the run did move (the LML rose by more than a nat)
+    # and with the default (loose) stopping rule the device run still reaches the oracle's optimum to 1e-4
+    m2 = gpo.models.GPRegression(X, Y, kcls(D, 1.0, np.full(D if ard else 1, 0.5), ARD=bool(ard)), noise_var=0.1)
+    m2.optimize(max_iters=1000)
+    assert abs(m2.log_likelihood() + f_or_end) <= 1e-4 * abs(f_or_end)
+    m.close()
+    m2.close()

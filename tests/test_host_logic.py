@@ -185,3 +185,23 @@ def test_host_acquisitions_and_lp_evaluator_equal_oracle():
     np.random.seed(11)
     B0 = O.lp_compute_batch(TableLP(gm, sp, None, base), 4)
     np.testing.assert_array_equal(B1, B0)
+
+
+def test_bcast_fit_receiver_side_record():
+    """gp_comm_bcast_fit's receiver side (api_comm.hip: pack_fit_record / apply_fit_record), driven host-only through
+    gp_comm_selftest_fit_record: RCCL with two ranks cannot run on a one-GPU lease, so the state a receiving rank ends
+    up in -- the ROOT's jitter / LML / log det, fitted, and every result derived from its previous factor dropped -- is
+    pinned here (run.py:1240-1241 scores shards against replicas of one fit)."""
+    import ctypes
+    from gaussian_process_optimization_amd import _lib
+    lib = _lib.load_library()
+    root = np.array([3.5e-6, -1234.56789, 4321.125])
+    state = np.zeros(3)
+    flags = (ctypes.c_int * 6)()
+    rc = lib.gp_comm_selftest_fit_record(_lib.dptr(root), _lib.dptr(state), flags)
+    assert rc == 0
+    assert np.array_equal(state, root)                      # bitwise: the record is moved, not recomputed
+    fitted, fmin_valid, wi_valid, invp_valid, lr_valid, predicted = list(flags)
+    assert fitted == 1
+    assert [fmin_valid, wi_valid, invp_valid, lr_valid, predicted] == [0, 0, 0, 0, 0]
+    assert lib.gp_comm_selftest_fit_record(None, _lib.dptr(state), flags) == _lib.GP_ERR_ARG

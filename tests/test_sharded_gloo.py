@@ -13,7 +13,9 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    from gaussian_process_optimization_amd.sharded import ShardedCandidates, TorchCollective
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gaussian_process_optimization_amd.sharded import ShardedCandidates
+    from _collective import TorchCollective
     from oracle import cpu_ref as O
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:

@@ -372,7 +372,9 @@ class Handle(object):
         return [dict(name=names[i].decode(), ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(max(n, 0))]
 
     def profile(self, on=True):
-        check(self.lib, self.lib.gp_profile(self.h, int(bool(on))), "gp_profile")
+        """on: False/0 off, True/1 events around every launch of the dominant GEMM symbol (8 waves, 128-tiles), 2 around
+        every launch of the 64 x 64 work-unit symbol instead (stalls the latency chain: for an un-timed pass only)."""
+        check(self.lib, self.lib.gp_profile(self.h, int(on)), "gp_profile")
 
     def gemm_stats(self):
         n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()

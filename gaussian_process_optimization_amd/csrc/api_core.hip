@@ -140,8 +140,12 @@ void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const double 
     // ~700 small launches of an iteration stalls the latency chain (34 -> 53 ms per factorisation, measured)
     // ... and only the launches of ONE kernel symbol, gemm_nt_kernel<1, 128, 4, false, 128> (C -= A B^T, 8 waves), so that the
     // average agrees with that symbol's row in a rocprofv3 --stats summary of the same command
-    const bool timed = g->profiling && n >= g->profile_min_tiles &&
-                       (g->profile_min_tiles < 1024 || (mode == 1 && oo.waves8 && !oo.small));  // tracing tools lower the threshold
+    // gp_profile(2) brackets the OTHER fp64 symbol instead, gemm_nt_kernel<1, 64, 2, false, 64> (C -= A B^T as 64 x 64 work
+    // units: the chain's in-panel / look-ahead updates and the short candidate updates) -- in a pass of its own, for the reason above
+    const bool small_sym = mode == 1 && oo.small && !oo.pair && !oo.rows64;
+    const bool timed = g->profiling && (g->profile_class == 1 ? small_sym :
+                       (n >= g->profile_min_tiles &&
+                        (g->profile_min_tiles < 1024 || (mode == 1 && oo.waves8 && !oo.small))));  // tracing tools lower the threshold
     if (timed) {
         if (g->gemm_ev_used + 2 > g->gemm_events.size()) {
             hipEvent_t a, b;

@@ -119,6 +119,7 @@ struct gp_ctx {
     Phase phases[MAX_PHASES];
     int nphases = 0;
     bool profiling = false;
+    int profile_class = 0;   // which kernel symbol gp_profile brackets: 0 = the 8-wave 128-tile update, 1 = the 64 x 64 work-unit update
     std::vector<hipEvent_t> gemm_events;
     std::vector<hipEvent_t> rns_events;   // gp_profile: start / end of every residue GEMM launch (rns_gemm256_kernel)
     size_t rns_ev_used = 0;

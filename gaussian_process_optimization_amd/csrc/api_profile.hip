@@ -23,6 +23,7 @@ extern "C" int gp_profile(gp_t *g, int on) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
     GP_DEAD_CHECK(g);
     g->profiling = on != 0;
+    g->profile_class = on == 2 ? 1 : 0;
     g->gemm_ev_used = 0;
     g->gemm_tiles.clear();
     g->gemm_K.clear();

@@ -232,7 +232,10 @@ int gp_last_phases(gp_t *gp, int cap, const char **names, double *ms, double *fl
  * when profiling is on), algorithmic flops.  With the default threshold the events bracket exactly the launches of one
  * kernel symbol, gemm_nt_kernel<1, 128, 4, false, 128> (C -= A B^T, >= 1400 output tiles), so that the average agrees with that
  * symbol's row of a rocprofv3 --stats summary; "profile_min_tiles" < 1024 brackets every launch above it instead
- * (tracing tools).  Reset by gp_profile(gp, 1). */
+ * (tracing tools).  Reset by gp_profile(gp, 1).  gp_profile(gp, 2) brackets the launches of the second fp64 symbol instead,
+ * gemm_nt_kernel<1, 64, 2, false, 64> (the same update as 64 x 64 work units: the factorisation chain's in-panel and
+ * look-ahead updates, short candidate updates); events around those ~100-us launches stall the chain, so this is for a
+ * pass outside any timed region. */
 int gp_profile(gp_t *gp, int on);
 int gp_gemm_stats(gp_t *gp, int64_t *launches, double *ms, double *flops);
 /* the same for the residue GEMM of "emulate_fp64" (rns_gemm256_kernel, every launch): launches, summed device time, int8

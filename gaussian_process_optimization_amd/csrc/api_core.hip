@@ -424,6 +424,9 @@ extern "C" int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N,
         HIPCHK(hipMalloc((void **)&g->dY, sizeof(double) * capN * capP));
         HIPCHK(hipMalloc((void **)&g->dA, sizeof(double) * (capN + GP_MAX_RHS) * capN));
         HIPCHK(hipMalloc((void **)&g->dInvL, sizeof(double) * capN * GP_TILE));
+        // the diagonal-tile kernel writes the lower block triangle of each inverted tile only (potrf.hip): the blocks above
+        // it are zero from here on
+        HIPCHK(hipMemsetAsync(g->dInvL, 0, sizeof(double) * capN * GP_TILE, g->s));
         HIPCHK(hipMalloc((void **)&g->dAlpha, sizeof(double) * capN * capP));
         HIPCHK(hipMalloc((void **)&g->dW, sizeof(double) * capN * capP));
         HIPCHK(hipMalloc((void **)&g->dMu, sizeof(double) * capN * 16));

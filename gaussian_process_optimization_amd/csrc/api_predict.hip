@@ -303,6 +303,8 @@ extern "C" int gp_posterior_samples(gp_t *g, int include_noise, const double *Z,
     double *invL = g->dT;
     const int mt = (int)(Mpad / GP_TILE), st = (int)(Spad / GP_TILE);
     HIPCHK(hipMemsetAsync(Zd, 0, sizeof(double) * Spad * Mpad, g->s));
+    // (the diagonal-tile kernel writes the lower block triangle of an inverted tile only; dT held candidate rows before)
+    HIPCHK(hipMemsetAsync(invL, 0, sizeof(double) * Mpad * GP_TILE, g->s));
     HIPCHK(hipMemcpy2DAsync(Zd, sizeof(double) * Mpad, Z, sizeof(double) * M, sizeof(double) * M, S,
                             hipMemcpyHostToDevice, g->s));
     // jitchol scales its ladder by the mean of the diagonal of the matrix it factors (linalg.py:62-66: diagA.mean() * 1e-6):

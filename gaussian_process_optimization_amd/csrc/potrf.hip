@@ -1,4 +1,4 @@
-// Diagonal-tile Cholesky + triangular inverse for gfx950 (one workgroup per 128x128 tile).
+// Diagonal-tile Cholesky + triangular inverse for gfx950 (one workgroup of eight waves per 128x128 tile).
 //
 // Replaces the unblocked part of LAPACK dpotrf (reference call site GPy/GPy/util/linalg.py:58)
 // and supplies L11^-1 so that every panel / candidate triangular solve above it becomes a
@@ -6,21 +6,27 @@
 // exact_gaussian_inference.py:60).
 //
 // The tile lives in LDS (pitch 130 doubles: the MFMA operand pattern row=lane&15, k=lane>>4 read
-// with ds_read_b64 is conflict free since 130 = 2 mod 32).  Factorisation is right-looking over
-// eight 16-column micro panels:
-//   (1) wave 0 factors the 16x16 diagonal micro block entirely in registers (lane (i, g) owns
-//       columns g, g+4, g+8, g+12 of row i; pivots/columns move by readlane / ds_bpermute; L D L^T
-//       elimination so that only a reciprocal sits between consecutive pivots) and inverts it by
-//       forward substitution (column per lane) -- while the other seven waves apply the previous
-//       micro panel's trailing update (one micro block of look-ahead inside the tile);
-//   (2) the micro panel below is multiplied by that inverse (4 x v_mfma_f64_16x16x4_f64 per block);
-//   (3) the trailing 16x16 blocks take a rank-16 update (4 MFMAs each, A negated via the f64
-//       MFMA neg modifier so the old block value rides in as the C operand).
-// The tile inverse is then built block column by block column (one wave per column):
-//   Inv[i][j] = -Dinv[i] * sum_{k=j}^{i-1} L[i][k] Inv[k][j], the inner sum staying in the
-// accumulator and re-entering the next MFMA directly as its B operand (accumulator element s of
-// lane (n, g) is row 4s+g, column n -- exactly the B fragment of k-step s).  Inverse blocks are
-// parked transposed in the unused upper triangle of the LDS tile.
+// with ds_read_b64 is conflict free since 130 = 2 mod 32).  This kernel is the serial link of the factorisation's
+// latency chain (one launch per 128 columns), so it is organised around its own critical path:
+//
+//  Factorisation, right-looking over eight 16-column micro panels p:
+//   E(p)  ELIMINATION IN REGISTERS.  A wave holds, one row per lane, the 16 x 16 diagonal micro block (lanes 0-15) and up
+//         to three 16-row blocks of the panel below it (lanes 16-63), all 16 columns of a row in registers.  The 16 pivot
+//         steps  a_ij -= (a_ik / a_kk) a_jk  take a_kk and a_jk from the diagonal block's lanes through v_readlane (wave-
+//         uniform scalars feeding the FMAs); the only arithmetic between two pivots is one reciprocal (L D L^T order).
+//         The rows below the diagonal block come out SOLVED by the same steps -- no inverse of the micro block sits on the
+//         chain (round 2 inverted it by substitution inside the chain: 7.4k cycles per micro panel for factor + inverse,
+//         then a product per row block).  Columns are scaled by 1/sqrt(d_j) afterwards, all at once.
+//   Uc(p) the 16-column block column p+1 takes panel p's rank-16 update on the matrix pipe (one block per wave, 4 MFMAs):
+//         all that E(p+1) waits for.
+//   Ur(p) every other trailing block takes it WHILE E(p+1) runs, on the waves that do not eliminate.
+//  Inverse by 2 x 2 block recursion, Inv[J][I] = -Inv[J][J] L[J][I] Inv[I][I]: the eight 16 x 16 diagonal inverses by
+//  substitution, one per wave, in parallel; then levels of 32, 64 and 128 rows, each as two rounds of independent block
+//  products spread evenly over the eight waves (the intermediate L[J][I] Inv[I][I] overwrites L[J][I] in LDS: the factor
+//  has gone to HBM by then).  Round 2 built it block column by block column: 168 dependent MFMAs on wave 0.
+//  Loads / stores cover the lower block triangle only (the inverse's upper blocks are zero from the allocation on) and ride
+//  beside the arithmetic: block column 0 is loaded first and the rest arrives during E(0); the factor leaves block column
+//  by block column during the following micro panel, the inverse level by level.
 #include "gphip_internal.h"
 
 #ifdef POTRF_STAMPS
@@ -73,59 +79,140 @@ __device__ __forceinline__ void sqrt_rsqrt(double a, double &sq, double &rsq) {
     rsq = 2.0 * h;
 }
 
-// Factor the 16x16 micro block p of T in place and write its inverse to Dinv[p].  One wave.
-// Lane (i = lane&15, g = lane>>4) owns columns g, g+4, g+8, g+12 of row i.
-//
-// The elimination runs in L D L^T form: at step k the trailing entries take
-//   a_ij -= a_ik a_jk / a_kk
-// with the UNSCALED column k, so the only arithmetic between two consecutive pivots is one reciprocal
-// (seed + 2 Newton steps) and one FMA; the cross-lane fetches of a_ik, a_jk (ds_bpermute) are issued before
-// the reciprocal is ready, and the square roots that turn L' D^1/2 into the Cholesky factor are taken
-// afterwards, all 16 at once, off the chain.  Returns the first failing local column (0..15) or -1.
-__device__ __forceinline__ int potrf16_inv16(double *T, double *Dinv, int p, int lane) {
-    const int li = lane & 15, lg = lane >> 4;
-    double *blk = T + (p * 16 + li) * TS + p * 16;
-    double v[4];
+
+// ---- E: one wave eliminates micro panel p --------------------------------------------------------------------------------
+// Lane (g = lane >> 4, i = lane & 15): g = 0 holds row i of the diagonal micro block p, g = 1..3 row i of the row blocks
+// rb0 .. rb0+nrb-1 below it (lanes of missing blocks read a row of zeros at `zero` and write nothing).  Returns the first
+// failing local column (0..15) or -1.  Right of its diagonal the diagonal block is left with meaningless values: nothing
+// reads them (the factor's store, the substitution for its inverse and every block product stay on or below the diagonal).
+__device__ __forceinline__ int eliminate_panel(double *T, const double *zero, int p, int rb0, int nrb, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const bool valid = (g == 0) || (g <= nrb);
+    const int rb = (g == 0) ? p : rb0 + g - 1;
+    double *rowp = T + (rb * 16 + i) * TS + p * 16;
+    const double *src = valid ? rowp : zero;
+    double a[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = blk[lg + 4 * q];
-    int fail = -1;
-    double piv_own = 1.0;  // pivot d_i of this lane's row
+    for (int q = 0; q < 8; ++q) {
+        const double2_t v = *(const double2_t *)(src + 2 * q);
+        a[2 * q] = v[0];
+        a[2 * q + 1] = v[1];
+    }
+    double piv = 1.0;   // d_i collects in lane i (1.0 elsewhere)
 #pragma unroll
-    for (int k = 0; k < 15; ++k) {
-        const int kq = k >> 2, kg = k & 3;
-        const double aik = __shfl(v[kq], li + 16 * kg);
-        double t[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = aik * __shfl(v[kq], lg + 4 * q + 16 * kg);
-        const double akk = readlane_d(v[kq], k + 16 * kg);
-        if (!(akk > 0.0) && fail < 0) fail = k;
-        if (li == k) piv_own = akk;
+    for (int k = 0; k < 16; ++k) {
+        const double akk = readlane_d(a[k], k);
+        if (lane == k) piv = akk;
         const double rk = fast_rcp(akk);
+        const double m = a[k] * rk;                 // a_ik / a_kk
+        // a_jk (row j of the diagonal block) through v_readlane, four at a time: the scalar results of one group are
+        // consumed by the FMAs while the next group's reads issue (a VALU read of a just-written SGPR costs wait states)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = lg + 4 * q;
-            if (j > k && li >= j) v[q] = fma(-t[q], rk, v[q]);
+        for (int j0 = k + 1; j0 < 16; j0 += 4) {
+            double s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] = (j0 + u < 16) ? readlane_d(a[k], j0 + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < 16) a[j0 + u] = fma(-m, s[u], a[j0 + u]);
         }
     }
-    {
-        const double a15 = readlane_d(v[3], 15 + 16 * 3);
-        if (!(a15 > 0.0) && fail < 0) fail = 15;
-        if (li == 15) piv_own = a15;
-    }
-    // scale: L[i][j] = a_ij / sqrt(d_j) (j < i), L[i][i] = sqrt(d_i)
-    double sq_own, rs_own;
-    sqrt_rsqrt(piv_own, sq_own, rs_own);
+    const unsigned long long bad = __ballot(!(piv > 0.0)) & 0xFFFFull;
+    const int fail = bad ? (int)__builtin_ctzll(bad) : -1;
+    double sq, rs;
+    sqrt_rsqrt(piv, sq, rs);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int j = lg + 4 * q;
-        const double rsj = __shfl(rs_own, j);  // lane j (g = 0) holds row j's pivot
-        v[q] = (j < li) ? v[q] * rsj : ((j == li) ? sq_own : 0.0);
-        blk[j] = v[q];
+    for (int j = 0; j < 16; ++j) a[j] *= readlane_d(rs, j);   // L[i][j] = a_ij / sqrt(d_j)
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            double2_t v;
+            v[0] = a[2 * q];
+            v[1] = a[2 * q + 1];
+            *(double2_t *)(rowp + 2 * q) = v;
+        }
+        if (g == 0) rowp[i] = sq;   // L[i][i] = sqrt(d_i): lands after the row (one wave's LDS operations execute in order)
     }
-    // inverse by forward substitution, column li per lane; L[i][k] comes back as an LDS broadcast read
-    // (same address in every lane) of what this wave just stored -- DS operations of one wave execute in order.
-    // Two partial sums per row halve the dependent FMA chain.
+    return fail;
+}
+
+// trailing block (i, j) -= X_i X_j^T with the solved micro panel p (rank 16: 4 MFMAs, as two independent pairs so that
+// the dependent chain on the factorisation's critical path is two matrix instructions, not four)
+__device__ __forceinline__ void update_block(double *T, int p, int i, int j, int li, int lg) {
+    const double *ap = T + (i * 16 + li) * TS + p * 16 + lg;
+    const double *bp = T + (j * 16 + li) * TS + p * 16 + lg;
+    double *cp = T + (i * 16 + lg) * TS + j * 16 + li;
+    const double a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+    const double b0 = bp[0], b1 = bp[4], b2 = bp[8], b3 = bp[12];
+    double4_t acc, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = cp[(4 * r) * TS];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 1);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc2, 0, 0, 1);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 1);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc2, 0, 0, 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cp[(4 * r) * TS] = acc[r] + acc2[r];
+}
+
+// ---- operand fetch / result store of the inverse's block products (element (row, col) of a 16 x 16 block) ------------------
+//   A operand of MFMA step s: A[li][lg + 4s];  B operand: B[lg + 4s][li];  result r of lane (li, lg): D[4r + lg][li]
+struct Frag { double v[4]; };
+__device__ __forceinline__ Frag lda_rowmajor(const double *base, int pitch, int li, int lg) {    // A[m][k] at base + m pitch + k
+    Frag f; const double *q = base + li * pitch + lg;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.v[s] = q[4 * s];
+    return f;
+}
+__device__ __forceinline__ Frag lda_transposed(const double *base, int pitch, int li, int lg) {  // A[m][k] at base + k pitch + m
+    Frag f; const double *q = base + lg * pitch + li;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.v[s] = q[(4 * s) * pitch];
+    return f;
+}
+__device__ __forceinline__ Frag ldb_rowmajor(const double *base, int pitch, int li, int lg) {    // B[k][n] at base + k pitch + n
+    Frag f; const double *q = base + lg * pitch + li;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.v[s] = q[(4 * s) * pitch];
+    return f;
+}
+__device__ __forceinline__ Frag ldb_transposed(const double *base, int pitch, int li, int lg) {  // B[k][n] at base + n pitch + k
+    Frag f; const double *q = base + li * pitch + lg;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.v[s] = q[4 * s];
+    return f;
+}
+template <int NEG>
+__device__ __forceinline__ double4_t mma(const Frag &a, const Frag &b, double4_t acc) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[s], b.v[s], acc, 0, 0, NEG);
+    return acc;
+}
+__device__ __forceinline__ Frag acc_as_b(const double4_t &P) {   // an accumulator re-enters as the B operand: P[4s + lg][li]
+    Frag f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.v[s] = P[s];
+    return f;
+}
+__device__ __forceinline__ void st_rowmajor(double *base, int pitch, int li, int lg, const double4_t &acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) base[(4 * r + lg) * pitch + li] = acc[r];
+}
+__device__ __forceinline__ void st_transposed(double *base, int pitch, int li, int lg, const double4_t &acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) base[li * pitch + 4 * r + lg] = acc[r];
+}
+// Where things live during the inverse:  L[i][j] (i >= j) row-major in T's lower blocks;  Dinv[b]: the inverse of
+// diagonal micro block b, row-major, pitch DS;  Inv[i][j] (i > j) PARKED TRANSPOSED in T's upper block (j, i):
+// T[(16 j + n) TS + 16 i + m] = Inv_ij[m][n];  the intermediate P[k][c] = (L[J][I] Inv[I][I])_kc overwrites L[k][c].
+#define TBLK(i, j) (T + ((i) * 16) * TS + (j) * 16)
+
+// Inverse of the 16x16 diagonal micro block p (forward substitution, column li per lane; L[i][k] comes back as LDS broadcast
+// reads; two partial sums per row halve the dependent FMA chain).  One wave; lanes 0-15 write.
+__device__ __forceinline__ void inv16(const double *T, double *Dinv, int p, int lane) {
+    const int li = lane & 15, lg = lane >> 4;
     const double *row = T + (p * 16) * TS + p * 16;
+    const double rinv = fast_rcp(row[li * TS + li]);   // 1 / L_ii of this lane's row
     double m[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -135,167 +222,236 @@ __device__ __forceinline__ int potrf16_inv16(double *T, double *Dinv, int p, int
             if (k & 1) s1 = fma(-row[i * TS + k], m[k], s1);
             else s0 = fma(-row[i * TS + k], m[k], s0);
         }
-        const double rii = __shfl(rs_own, i);
-        m[i] = (s0 + s1) * rii;
+        m[i] = (s0 + s1) * readlane_d(rinv, i);
     }
     if (lg == 0) {
         double *dp = Dinv + p * DBLK + li;
 #pragma unroll
         for (int i = 0; i < 16; ++i) dp[i * DS] = m[i];
     }
-    return fail;
 }
 
-// one 16x16 block product on the matrix pipe: acc (+)= sum_k A[i][k] B[j][k], operands in LDS with pitches
-// (pa, pb); neg selects acc - A B^T through the f64 MFMA's neg-A modifier.
-template <int NEG>
-__device__ __forceinline__ double4_t mm16(const double *ap, const double *bp, int sb, double4_t acc) {
-    const double a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
-    const double b0 = bp[0], b1 = bp[4 * sb], b2 = bp[8 * sb], b3 = bp[12 * sb];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, NEG);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, NEG);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, NEG);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, NEG);
-    return acc;
+// the inverse's finished blocks go to the workspace as soon as a level is complete (stores overlap the next level's
+// products).  nb blocks of 16 x 16, 128 16-byte chunks each; block b of a level sits at (rb, cb):
+//   level 0: the diagonal micro blocks (b, b), from Dinv;  level 1: (2b+1, 2b);  level 2: (4Q+2+((b>>1)&1), 4Q+(b&1)),
+//   Q = b>>2;  level 3: (4 + (b>>2), b&3) -- off-diagonal blocks are read back from where they are parked (transposed).
+template <int LEVEL>
+__device__ __forceinline__ void store_inverse_level(double *Iv, const double *T, const double *Dinv, int tid) {
+    constexpr int nb = LEVEL == 0 ? 8 : (LEVEL == 1 ? 4 : (LEVEL == 2 ? 8 : 16));
+#pragma unroll
+    for (int q = 0; q < (nb * 128 + 511) / 512; ++q) {
+        const int e = tid + 512 * q;
+        if (e >= nb * 128) break;
+        const int b = e >> 7, rr = (e & 127) >> 3, cc = (e & 7) * 2;
+        int rb, cb;
+        if (LEVEL == 0) { rb = b; cb = b; }
+        else if (LEVEL == 1) { rb = 2 * b + 1; cb = 2 * b; }
+        else if (LEVEL == 2) { rb = 4 * (b >> 2) + 2 + ((b >> 1) & 1); cb = 4 * (b >> 2) + (b & 1); }
+        else { rb = 4 + (b >> 2); cb = b & 3; }
+        const int r = rb * 16 + rr, c = cb * 16 + cc;
+        double2_t v;
+        if (LEVEL == 0) {
+            v = *(const double2_t *)(Dinv + rb * DBLK + rr * DS + cc);
+        } else {
+            v[0] = T[c * TS + r];
+            v[1] = T[(c + 1) * TS + r];
+        }
+        *(double2_t *)(Iv + r * GP_TILE + c) = v;
+    }
 }
 
-// Factor + invert tile t of A (see the header).
-// T: GP_TILE * TS doubles of LDS, Dinv: 8 * DBLK doubles of LDS.  512 threads.
+// the factor's block column p (rows 16 p .. 127; on or below the diagonal only) goes to HBM: `nthreads` threads, this
+// thread's index among them `th`
+__device__ __forceinline__ void store_factor_column(double *At, long lda, const double *T, int p, int th, int nthreads) {
+    const int nchunk = (128 - 16 * p) * 8;
+    for (int e = th; e < nchunk; e += nthreads) {
+        const int r = 16 * p + (e >> 3), c = 16 * p + (e & 7) * 2;
+        const double2_t v = *(const double2_t *)(T + r * TS + c);
+        if (c + 1 <= r) *(double2_t *)(At + (long)r * lda + c) = v;
+        else if (c == r) At[(long)r * lda + c] = v[0];
+    }
+}
+
+// Factor + invert tile t of A (see the header).  T: GP_TILE * TS doubles of LDS, Dinv: 8 * DBLK doubles of LDS.  512 threads.
 __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, double *invL, int *info, double *T, double *Dinv) {
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     double *At = A + (long)t * GP_TILE * lda + (long)t * GP_TILE;
+    double *Iv = invL + (long)t * GP_TILE * GP_TILE;
     STAMP(0);
 
-    // load the lower part (whole rows: simpler and coalesced), 16 B per lane
-    for (int q = 0; q < 16; ++q) {
-        const int id = tid + 512 * q;
-        const int r = id >> 6, c2 = (id & 63) * 2;
-        const double2_t v = *(const double2_t *)(At + (long)r * lda + c2);
-        *(double2_t *)(T + r * TS + c2) = v;
-    }
-    __syncthreads();
-    STAMP(1);
-    if (wave == 0) {
-        const int fail = potrf16_inv16(T, Dinv, 0, lane);
-        if (fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + fail + 1);
-    }
-    __syncthreads();
-
-    // Right-looking over eight 16-column micro panels with one micro block of look-ahead:
-    //   stage A  wave 0: row block p+1 of the panel solve;      waves 1..7: row blocks p+2..7
-    //   stage B  wave 0: update of block (p+1,p+1), then its factorisation + inverse (the latency chain);
-    //            waves 1..7: every other trailing block (i, j), p < j <= i, (i, j) != (p+1, p+1)
-    STAMP(2);
-    for (int p = 0; p < 7; ++p) {
-        STAMP(3 + 3 * p);
-        {   // stage A: X = T[rb][p] * Dinv[p]^T
-            const int rb = p + 1 + wave;
-            if (rb < 8) {
-                const double *ap = T + (rb * 16 + li) * TS + p * 16 + lg;
-                const double *bp = Dinv + p * DBLK + li * DS + lg;
-                double4_t acc = {0.0, 0.0, 0.0, 0.0};
-                acc = mm16<0>(ap, bp, 1, acc);
-                double *cp = T + (rb * 16 + lg) * TS + p * 16 + li;
+    // ---- load: block column 0 first (all E(0) needs), the rest of the lower block triangle (diagonal micro blocks in full:
+    //      the input is symmetric there) by waves 3..7 while waves 0..2 eliminate micro panel 0 ----
+    {
+        double2_t c0[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cp[(4 * r) * TS] = acc[r];
+        for (int q = 0; q < 2; ++q) {
+            const int id = tid + 512 * q;               // 128 rows x 8 chunks
+            c0[q] = *(const double2_t *)(At + (long)(id >> 3) * lda + (id & 7) * 2);
+        }
+        double2_t rest[12];
+        if (wave >= 3) {
+            // chunks of block columns 1..7, rows from the column's diagonal block down: 28 blocks x 128 chunks = 3584,
+            // enumerated block by block (block e >> 7 of the list: column cb = 1..7, row rb = cb..7), 320 threads x 12 (11.2)
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const int e = (tid - 192) + 320 * q;
+                if (e < 3584) {
+                    const int b = e >> 7;
+                    int cb = 1, rem = b;
+                    while (rem >= 8 - cb) { rem -= 8 - cb; ++cb; }     // wave-divergent but tiny (<= 7 steps)
+                    const int rb = cb + rem;
+                    const int r = rb * 16 + ((e & 127) >> 3), c = cb * 16 + (e & 7) * 2;
+                    rest[q] = *(const double2_t *)(At + (long)r * lda + c);
+                }
             }
         }
+        if (tid < 16) Dinv[tid] = 0.0;                   // the row of zeros E's idle lanes read
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int id = tid + 512 * q;
+            *(double2_t *)(T + (id >> 3) * TS + (id & 7) * 2) = c0[q];
+        }
         __syncthreads();
-        STAMP(4 + 3 * p);
-        if (wave == 0) {
-            const int i = p + 1;
-            const double *ap = T + (i * 16 + li) * TS + p * 16 + lg;
-            double *cp = T + (i * 16 + lg) * TS + i * 16 + li;
-            double4_t acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = cp[(4 * r) * TS];
-            acc = mm16<1>(ap, ap, 1, acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cp[(4 * r) * TS] = acc[r];
-            const int fail = potrf16_inv16(T, Dinv, i, lane);
-            if (fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + i * 16 + fail + 1);
-            STAMP(5 + 3 * p);
+        STAMP(1);
+        // phase 1 of micro panel 0:  E(0) on waves 0..2  ||  the rest of the tile lands in LDS
+        if (wave < 3) {
+            const int rb0 = 1 + 3 * wave;
+            const int fail = eliminate_panel(T, Dinv, 0, rb0, min(3, 8 - rb0), lane);
+            if (wave == 0 && fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + fail + 1);
         } else {
-            // blocks (i, j), p+1 <= j <= i <= 7 without (p+1, p+1): enumerate rows i = p+1 .. 7
-            const int nb = 7 - p;
-            const int cnt = nb * (nb + 1) / 2 - 1;
-            for (int e = wave - 1; e < cnt; e += 7) {
-                const int e1 = e + 1;  // skip entry 0 = (p+1, p+1)
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= e1) ++ii;
-                const int jj = e1 - ii * (ii + 1) / 2;
-                const int i = p + 1 + ii, j = p + 1 + jj;
-                const double *ap = T + (i * 16 + li) * TS + p * 16 + lg;
-                const double *bp = T + (j * 16 + li) * TS + p * 16 + lg;
-                double *cp = T + (i * 16 + lg) * TS + j * 16 + li;
-                double4_t acc;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = cp[(4 * r) * TS];
-                acc = mm16<1>(ap, bp, 1, acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cp[(4 * r) * TS] = acc[r];
+            for (int q = 0; q < 12; ++q) {
+                const int e = (tid - 192) + 320 * q;
+                if (e < 3584) {
+                    const int b = e >> 7;
+                    int cb = 1, rem = b;
+                    while (rem >= 8 - cb) { rem -= 8 - cb; ++cb; }
+                    const int rb = cb + rem;
+                    const int r = rb * 16 + ((e & 127) >> 3), c = cb * 16 + (e & 7) * 2;
+                    *(double2_t *)(T + r * TS + c) = rest[q];
+                }
             }
         }
         __syncthreads();
     }
 
-    STAMP(24);
-    // ---- tile inverse, block column j = wave; Inv[i][j] parked at T[(j16+n)][(i16+m)] = Inv_ij[m][n]
-    for (int i = 1; i < 8; ++i) {
-        const int j = wave;
-        if (i > j) {
-            double4_t P = {0.0, 0.0, 0.0, 0.0};
-            {   // k = j term: L[i][j] * Dinv[j]
-                const double *ap = T + (i * 16 + li) * TS + j * 16 + lg;
-                const double *bp = Dinv + j * DBLK + lg * DS + li;
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    P = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s], bp[(4 * s) * DS], P, 0, 0, 0);
+    // ---- factorisation ---------------------------------------------------------------------------------------------
+    for (int p = 0; p < 8; ++p) {
+        STAMP(2 + 3 * p);
+        if (p >= 1) {
+            // phase 1:  E(p) on waves 0 .. nE-1  ||  on the others Ur(p-1) (blocks (i, j), p+1 <= j <= i, with panel p-1) and
+            //           the factor's finished block column p-1 on its way to HBM
+            const int nrows = 7 - p;
+            const int nE = nrows > 0 ? (nrows + 2) / 3 : 1;
+            if (wave < nE) {
+                const int rb0 = p + 1 + 3 * wave;
+                const int nrb = min(3, 8 - rb0);
+                const int fail = eliminate_panel(T, Dinv, p, rb0, nrb > 0 ? nrb : 0, lane);
+                if (wave == 0 && fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + p * 16 + fail + 1);
+            } else {
+                const int cnt = nrows * (nrows + 1) / 2;
+                for (int e = wave - nE; e < cnt; e += 8 - nE) {
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
+                    const int jj = e - ii * (ii + 1) / 2;
+                    update_block(T, p - 1, p + 1 + ii, p + 1 + jj, li, lg);
+                }
+                store_factor_column(At, lda, T, p - 1, tid - 64 * nE, 512 - 64 * nE);
             }
-            for (int k = j + 1; k < i; ++k) {
-                const double *ap = T + (i * 16 + li) * TS + k * 16 + lg;
-                const double *bp = T + (j * 16 + li) * TS + k * 16 + lg;
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    P = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s], bp[4 * s], P, 0, 0, 0);
-            }
-            // Y = -Dinv[i] * P ; P re-enters as the B operand straight from the accumulator
-            double4_t Y = {0.0, 0.0, 0.0, 0.0};
-            const double *dp = Dinv + i * DBLK + li * DS + lg;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dp[4 * s], P[s], Y, 0, 0, 1);
-            double *cp = T + (j * 16 + li) * TS + i * 16 + lg;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cp[4 * r] = Y[r];
+            __syncthreads();
         }
-        __syncthreads();
+        STAMP(3 + 3 * p);
+        // phase 2:  Uc(p): block column p+1 takes panel p's update (block (p+1+wave, p+1))
+        if (p < 7) {
+            if (p + 1 + wave < 8) update_block(T, p, p + 1 + wave, p + 1, li, lg);
+            __syncthreads();
+        }
+        STAMP(4 + 3 * p);
     }
 
-    STAMP(25);
-    // ---- write back: L (lower incl. diagonal) in place, inverse tile to the workspace
-    double *Iv = invL + (long)t * GP_TILE * GP_TILE;
-    for (int q = 0; q < 32; ++q) {
-        const int id = tid + 512 * q;
-        const int r = id >> 7, c = id & 127;
-        if (c <= r) At[(long)r * lda + c] = T[r * TS + c];
-        double inv;
-        const int rb = r >> 4, cb = c >> 4;
-        if (rb == cb)
-            inv = Dinv[rb * DBLK + (r & 15) * DS + (c & 15)];
-        else if (rb > cb)
-            inv = T[c * TS + r];
-        else
-            inv = 0.0;
-        Iv[r * GP_TILE + c] = inv;
-    }
     STAMP(26);
+    // ---- inverse: diagonal micro blocks, one per wave; the factor's last block column goes out meanwhile ----
+    store_factor_column(At, lda, T, 7, tid, 512);
+    inv16(T, Dinv, wave, lane);
+    __syncthreads();
+    STAMP(27);
+    store_inverse_level<0>(Iv, T, Dinv, tid);
+    // level 1: pairs (2q, 2q+1):  Inv[i][j] = -Dinv[i] (L[i][j] Dinv[j]),  i = j + 1
+    if (wave < 4) {
+        const int j = 2 * wave, i = j + 1;
+        double4_t P = {0.0, 0.0, 0.0, 0.0}, Y = {0.0, 0.0, 0.0, 0.0};
+        P = mma<0>(lda_rowmajor(TBLK(i, j), TS, li, lg), ldb_rowmajor(Dinv + j * DBLK, DS, li, lg), P);
+        Y = mma<1>(lda_rowmajor(Dinv + i * DBLK, DS, li, lg), acc_as_b(P), Y);
+        st_transposed(TBLK(j, i), TS, li, lg, Y);
+    }
+    __syncthreads();
+    STAMP(28);
+    store_inverse_level<1>(Iv, T, Dinv, tid);
+    // level 2: quads Q = 0, 1:  I = {4Q, 4Q+1}, J = {4Q+2, 4Q+3}
+    {
+        const int Q = wave >> 2, I0 = 4 * Q, J0 = 4 * Q + 2;
+        const int k = J0 + ((wave >> 1) & 1), c = I0 + (wave & 1);
+        // P[k][c] = sum_{m in I, m >= c} L[k][m] Inv[m][c]
+        double4_t P = {0.0, 0.0, 0.0, 0.0};
+        P = mma<0>(lda_rowmajor(TBLK(k, c), TS, li, lg), ldb_rowmajor(Dinv + c * DBLK, DS, li, lg), P);
+        if (c == I0) P = mma<0>(lda_rowmajor(TBLK(k, I0 + 1), TS, li, lg), ldb_transposed(TBLK(I0, I0 + 1), TS, li, lg), P);
+        __syncthreads();                       // every L block of the level has been read
+        st_rowmajor(TBLK(k, c), TS, li, lg, P);
+        __syncthreads();
+        // Inv[r][c] = -sum_{k' in J, k' <= r} Inv[r][k'] P[k'][c]
+        const int r = k;
+        double4_t Y = {0.0, 0.0, 0.0, 0.0};
+        if (r == J0 + 1) Y = mma<1>(lda_transposed(TBLK(J0, J0 + 1), TS, li, lg), ldb_rowmajor(TBLK(J0, c), TS, li, lg), Y);
+        Y = mma<1>(lda_rowmajor(Dinv + r * DBLK, DS, li, lg), ldb_rowmajor(TBLK(r, c), TS, li, lg), Y);
+        st_transposed(TBLK(c, r), TS, li, lg, Y);
+    }
+    __syncthreads();
+    STAMP(29);
+    store_inverse_level<2>(Iv, T, Dinv, tid);
+    // level 3: I = {0..3}, J = {4..7}; every wave runs two independent accumulation chains (5 block products in all)
+    {
+        // P[k][c] = sum_{m = c..3} L[k][m] Inv[m][c]: wave w takes row k = 4 + (w >> 1), columns c1 = w & 1 and c2 = 3 - c1
+        const int k = 4 + (wave >> 1);
+        const int c1 = wave & 1, c2 = 3 - c1;
+        double4_t P1 = {0.0, 0.0, 0.0, 0.0}, P2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (c1 + s < 4)
+                P1 = mma<0>(lda_rowmajor(TBLK(k, c1 + s), TS, li, lg),
+                            s == 0 ? ldb_rowmajor(Dinv + c1 * DBLK, DS, li, lg) : ldb_transposed(TBLK(c1, c1 + s), TS, li, lg), P1);
+            if (c2 + s < 4)
+                P2 = mma<0>(lda_rowmajor(TBLK(k, c2 + s), TS, li, lg),
+                            s == 0 ? ldb_rowmajor(Dinv + c2 * DBLK, DS, li, lg) : ldb_transposed(TBLK(c2, c2 + s), TS, li, lg), P2);
+        }
+        __syncthreads();
+        st_rowmajor(TBLK(k, c1), TS, li, lg, P1);
+        st_rowmajor(TBLK(k, c2), TS, li, lg, P2);
+        __syncthreads();
+        // Inv[r][c] = -sum_{k' = 4..r} Inv[r][k'] P[k'][c]: wave w takes column c = w >> 1, rows r1 = 4 + (w & 1), r2 = 7 - (w & 1)
+        const int c = wave >> 1;
+        const int r1 = 4 + (wave & 1), r2 = 7 - (wave & 1);
+        double4_t Y1 = {0.0, 0.0, 0.0, 0.0}, Y2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kk = 4 + s;
+            if (kk <= r2) {   // (r1 <= r2)
+                const Frag b = ldb_rowmajor(TBLK(kk, c), TS, li, lg);
+                if (kk <= r1)
+                    Y1 = mma<1>(kk == r1 ? lda_rowmajor(Dinv + r1 * DBLK, DS, li, lg) : lda_transposed(TBLK(kk, r1), TS, li, lg), b, Y1);
+                Y2 = mma<1>(kk == r2 ? lda_rowmajor(Dinv + r2 * DBLK, DS, li, lg) : lda_transposed(TBLK(kk, r2), TS, li, lg), b, Y2);
+            }
+        }
+        st_transposed(TBLK(c, r1), TS, li, lg, Y1);
+        st_transposed(TBLK(c, r2), TS, li, lg, Y2);
+    }
+    __syncthreads();
+    STAMP(30);
+    store_inverse_level<3>(Iv, T, Dinv, tid);
+    STAMP(31);
 }
-
 
 __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, int t, double *invL, int *info) {
     __shared__ __attribute__((aligned(16))) double T[GP_TILE * TS];

@@ -146,7 +146,7 @@ def test_emulated_headline_configuration_full_size(h):
     assert np.max(np.abs(m1 - m0)) <= 1e-9 * np.max(np.abs(m0))
     assert np.max(np.abs(v1 - v0) / v0) <= 1e-9
     pick = np.unique(np.r_[np.linspace(0, M - 1, 62).astype(int), int(np.argmax(v1)), int(np.argmin(v1))])
-    lml0, _, alpha0, mu_o, var_o = _oracle_full_size(O.RBF(D, 1.0, ls), X, Y, 1e-2, Xs[pick])
+    lml0, _, alpha0, mu_o, var_o = _oracle_full_size(O.RBF(D, 1.0, ls), X, Y, 1e-2, Xs[pick], "c3")
     assert np.max(np.abs(m1[pick] - mu_o)) <= 1e-6 * np.max(np.abs(mu_o))
     assert np.max(np.abs(v1[pick] - var_o) / var_o) <= 1e-6
     print("emulated candidate solve phases (ms):", ph)
@@ -343,7 +343,7 @@ def test_emulated_fit_headline_configuration_full_size(h):
     finally:
         h.set_option("emulate_fp64", 0)
     pick = np.unique(np.r_[np.linspace(0, M - 1, 62).astype(int), int(np.argmax(v1)), int(np.argmin(v1))])
-    lml0, logdet0, alpha0, mu_o, var_o = _oracle_full_size(O.RBF(D, 1.0, ls), X, Y, 1e-2, Xs[pick])
+    lml0, logdet0, alpha0, mu_o, var_o = _oracle_full_size(O.RBF(D, 1.0, ls), X, Y, 1e-2, Xs[pick], "c3")
     assert abs(lml - lml0) <= 1e-8 * abs(lml0)
     assert abs(logdet - logdet0) <= 1e-8 * abs(logdet0)
     assert np.max(np.abs(alpha - alpha0)) <= 1e-6 * np.max(np.abs(alpha0))

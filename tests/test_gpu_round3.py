@@ -133,7 +133,11 @@ def test_optimize_same_x0_same_lbfgs_matches_oracle_objective(monkeypatch, mode,
     monkeypatch.setenv("GPHIP_EMULATE_FP64", str(mode))
     rng = np.random.default_rng(5 + N)
     X = rng.uniform(0, 1, (N, D))
-    Y = (np.sin(3 * X).sum(1, keepdims=True) + 0.1 * rng.standard_normal((N, 1)))
+    # a target with structure at the scale of the design (a well-conditioned optimum: variance ~ 2-5, lengthscales ~ 0.25-0.6;
+    # the smooth sum of sines of the first draft had a flat variance / lengthscale ridge along which two float64 runs of the
+    # same optimiser part by 2e-6)
+    w = np.array([9.0, 7.0, 11.0])[:D]
+    Y = (np.sin(X * w).sum(1, keepdims=True) + 0.3 * np.cos(13 * X[:, :1] * X[:, 1:2]) + 0.15 * rng.standard_normal((N, 1)))
     Y = (Y - Y.mean()) / Y.std()
     kcls = gpo.kern.RBF if kname == "rbf" else gpo.kern.Matern52
     m = gpo.models.GPRegression(X, Y, kcls(D, 1.0, np.full(D if ard else 1, 0.5), ARD=bool(ard)), noise_var=0.1)

@@ -101,6 +101,7 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
     const int Gf = (emu && !pp.on) ? std::max(1, std::min(g->rns_group_fit, (int)(GP_RNS_KMAX / PB))) : 1;
     hipStream_t sfar = g->s_pred;
     std::vector<char> far_issued(nJ / std::max(1, Gf) + 2, 0);
+    int mid_Jg = -1, mid_end = 0, mid_first = 0, mid_base = 0, mid_next = 0;
     if (Gf > 1) hipStreamWaitEvent(sfar, e0, 0);
     for (int J = 0; J < nJ; ++J) {
         const int J0 = pb[J], J1 = pb[J + 1], J2 = pb[J + 2];
@@ -161,13 +162,13 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
                 // the right-hand-side tile row rides in fp64
                 gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
                      TileSet{nt, R1, J2, nt, 0});
-                auto rlaunch = [&](hipStream_t st, int Jfirst, int t0, int t1, int first) {   // panels Jfirst..J -> tiles [t0, t1)
+                auto rlaunch = [&](hipStream_t st, int Jfirst, int t0, int t1, int first, int Tend = -1) {   // panels Jfirst..J (tiles up to Tend) -> tiles [t0, t1)
                     t1 = std::min(t1, nt);
                     if (t0 >= t1) return;
                     const int T0 = pb[Jfirst];
                     rns_gemm(g, st, g->dLr + (long)T0 * GP_TILE, rg.Lpitch, rg.Lplane, g->dLr + (long)T0 * GP_TILE, rg.Lpitch,
-                                       rg.Lplane, g->dRm, rg.nt256, rg.nt256, rg.nt256, t0 / 2, (t1 + 1) / 2, (J1 - T0) * GP_TILE,
-                                       first, 1);
+                                       rg.Lplane, g->dRm, rg.nt256, rg.nt256, rg.nt256, t0 / 2, (t1 + 1) / 2,
+                                       ((Tend < 0 ? J1 : Tend) - T0) * GP_TILE, first, 1);
                 };
                 auto pbi = [&](int k) { return pb[std::min(k, nJ + 1)]; };
                 // rebuild the columns of panel J+2 in fp64 (Ky minus everything accumulated for them: panels 0 .. J) as soon as
@@ -184,7 +185,9 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
                     // Panels in groups of Gf (all panel edges sit on 256-column accumulator blocks).  Pair (panel j, column
                     // panel c >= j+2; c = j+1 is the fp64 look-ahead) is served exactly once, by
                     //   near(J)  on the bulk stream, every iteration: the group's panels so far -> the columns of panel J+2,
-                    //   mid(g)   on the bulk stream, at the group's last panel: the whole group -> the next Gf column panels,
+                    //   mid(g)   on the bulk stream, from the group's last panel on, ONE column panel per iteration: the whole group
+                    //            -> the next Gf column panels, each slice an iteration before its columns are rebuilt (as one
+                    //            launch of 3.7 ms at N = 16384 it sat in front of near(J+1) and the chain stalled 2.6 ms behind it),
                     //   far(g)   on a stream of its own: the whole group -> everything right of that,
                     // so the accumulator makes one round trip per group for the far columns and the long launch (K = Gf PB)
                     // overlaps the next group's chain.  Ordering: near(J) and mid(g) accumulate into blocks far(g-1) / far(g-2)
@@ -200,13 +203,21 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
                     bulk_recorded = true;
                     if (J % Gf == Gf - 1) {
                         if (gi >= 1 && far_issued[gi - 1]) hipStreamWaitEvent(sb, la_event(g, EV_FAR, gi - 1), 0);
-                        rlaunch(sb, Jg, pbi(J + 3), pbi(J + 3 + Gf), first);
+                        mid_Jg = Jg;            // the slices of mid(g): column panel mid_base + k at iteration J + k
+                        mid_end = J1;
+                        mid_first = first;
+                        mid_base = J + 3;
+                        mid_next = 0;
                         if (pbi(J + 3 + Gf) < nt) {
                             hipStreamWaitEvent(sfar, la_event(g, EV_CONV, J), 0);
                             rlaunch(sfar, Jg, pbi(J + 3 + Gf), nt, first);
                             hipEventRecord(la_event(g, EV_FAR, gi), sfar);
                             far_issued[gi] = true;
                         }
+                    }
+                    if (mid_Jg >= 0 && mid_next < Gf) {
+                        rlaunch(sb, mid_Jg, pbi(mid_base + mid_next), pbi(mid_base + mid_next + 1), mid_first, mid_end);
+                        ++mid_next;
                     }
                 }
             } else {

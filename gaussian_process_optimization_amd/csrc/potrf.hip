@@ -21,9 +21,12 @@
 //         all that E(p+1) waits for.
 //   Ur(p) every other trailing block takes it WHILE E(p+1) runs, on the waves that do not eliminate.
 //  Inverse by 2 x 2 block recursion, Inv[J][I] = -Inv[J][J] L[J][I] Inv[I][I]: the eight 16 x 16 diagonal inverses by
-//  substitution, one per wave, in parallel; then levels of 32, 64 and 128 rows, each as two rounds of independent block
+//  substitution (seven of them beside E(4) .. E(7), the last beside the first level); then levels of 32, 64 and 128 rows, each as two rounds of independent block
 //  products spread evenly over the eight waves (the intermediate L[J][I] Inv[I][I] overwrites L[J][I] in LDS: the factor
 //  has gone to HBM by then).  Round 2 built it block column by block column: 168 dependent MFMAs on wave 0.
+//  What bounds it (cycle stamps, tools/micro/potrf_check): E is bound by one wave's instruction issue (3.6k cycles per micro
+//  panel: ~500 VALU instructions, a fifth of them f64); the trailing updates and the inverse by the f64 matrix instructions
+//  themselves (about 90 cycles each per SIMD here, 736 of them), which share the SIMD's f64 units with E's FMAs.
 //  Loads / stores cover the lower block triangle only (the inverse's upper blocks are zero from the allocation on) and ride
 //  beside the arithmetic: block column 0 is loaded first and the rest arrives during E(0); the factor leaves block column
 //  by block column during the following micro panel, the inverse level by level.
@@ -272,8 +275,10 @@ __device__ __forceinline__ void store_factor_column(double *At, long lda, const 
     }
 }
 
-// Factor + invert tile t of A (see the header).  T: GP_TILE * TS doubles of LDS, Dinv: 8 * DBLK doubles of LDS.  512 threads.
-__device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, double *invL, int *info, double *T, double *Dinv) {
+// Factor + invert tile t of A (see the header).  T: GP_TILE * TS doubles of LDS, Dinv: 8 * DBLK doubles of LDS, zrow: 16 zeros
+// in LDS.  512 threads.
+__device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, double *invL, int *info, double *T, double *Dinv,
+                                                const double *zrow) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -308,7 +313,6 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
                 }
             }
         }
-        if (tid < 16) Dinv[tid] = 0.0;                   // the row of zeros E's idle lanes read
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int id = tid + 512 * q;
@@ -319,7 +323,7 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
         // phase 1 of micro panel 0:  E(0) on waves 0..2  ||  the rest of the tile lands in LDS
         if (wave < 3) {
             const int rb0 = 1 + 3 * wave;
-            const int fail = eliminate_panel(T, Dinv, 0, rb0, min(3, 8 - rb0), lane);
+            const int fail = eliminate_panel(T, zrow, 0, rb0, min(3, 8 - rb0), lane);
             if (wave == 0 && fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + fail + 1);
         } else {
 #pragma unroll
@@ -345,21 +349,40 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
             // phase 1:  E(p) on waves 0 .. nE-1  ||  on the others Ur(p-1) (blocks (i, j), p+1 <= j <= i, with panel p-1) and
             //           the factor's finished block column p-1 on its way to HBM
             const int nrows = 7 - p;
-            const int nE = nrows > 0 ? (nrows + 2) / 3 : 1;
+            const int nE = nrows > 0 ? (nrows + 2) / 3 : 1;     // 2, 2, 2, 1, 1, 1, 1 for p = 1 .. 7
+            // The eliminating waves are bound by their own instruction issue: the waves that share their SIMDs (wave w + 4 sits
+            // on the SIMD of wave w) stay idle, the other 8 - 2 nE do the side work.  Worker index of a wave: its rank among
+            // them, or -1.
+            // (while 15 or more trailing blocks are waiting, p <= 2, every free wave is needed and the partners work too)
+            int worker = -1, nworkers = 8 - nE;
+            if (p <= 2) {
+                if (wave >= nE) worker = wave - nE;
+            } else {
+                nworkers = 8 - 2 * nE;
+                if (wave >= nE && !(wave >= 4 && wave < 4 + nE)) worker = wave < 4 ? wave - nE : wave - 2 * nE;
+            }
             if (wave < nE) {
+                __builtin_amdgcn_s_setprio(3);
                 const int rb0 = p + 1 + 3 * wave;
                 const int nrb = min(3, 8 - rb0);
-                const int fail = eliminate_panel(T, Dinv, p, rb0, nrb > 0 ? nrb : 0, lane);
+                const int fail = eliminate_panel(T, zrow, p, rb0, nrb > 0 ? nrb : 0, lane);
                 if (wave == 0 && fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + p * 16 + fail + 1);
-            } else {
+                __builtin_amdgcn_s_setprio(0);
+            } else if (worker >= 0) {
                 const int cnt = nrows * (nrows + 1) / 2;
-                for (int e = wave - nE; e < cnt; e += 8 - nE) {
+                for (int e = worker; e < cnt; e += nworkers) {
                     int ii = 0;
                     while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
                     const int jj = e - ii * (ii + 1) / 2;
                     update_block(T, p - 1, p + 1 + ii, p + 1 + jj, li, lg);
                 }
-                store_factor_column(At, lda, T, p - 1, tid - 64 * nE, 512 - 64 * nE);
+                store_factor_column(At, lda, T, p - 1, worker * 64 + lane, nworkers * 64);
+                // the diagonal micro blocks 0..6 are inverted here, two per window from micro panel 4 on (few trailing blocks
+                // are left by then; more than two substitutions at a time are bound by their LDS broadcast reads)
+                if (p >= 4 && worker >= 4) {
+                    const int blk = 2 * (p - 4) + (worker - 4);
+                    if (blk < 7) inv16(T, Dinv, blk, lane);
+                }
             }
             __syncthreads();
         }
@@ -373,20 +396,22 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
     }
 
     STAMP(26);
-    // ---- inverse: diagonal micro blocks, one per wave; the factor's last block column goes out meanwhile ----
-    store_factor_column(At, lda, T, 7, tid, 512);
-    inv16(T, Dinv, wave, lane);
-    __syncthreads();
-    STAMP(27);
-    store_inverse_level<0>(Iv, T, Dinv, tid);
-    // level 1: pairs (2q, 2q+1):  Inv[i][j] = -Dinv[i] (L[i][j] Dinv[j]),  i = j + 1
-    if (wave < 4) {
-        const int j = 2 * wave, i = j + 1;
+    // ---- inverse.  The diagonal micro blocks 0..6 were inverted beside E(4..7); block 7 follows now on wave 0 while waves 1..3
+    //      take the level-1 pairs that do not need it and the factor's last block column goes out ----
+    auto level1 = [&](int j) {   // pair (j, j+1):  Inv[i][j] = -Dinv[i] (L[i][j] Dinv[j]),  i = j + 1
+        const int i = j + 1;
         double4_t P = {0.0, 0.0, 0.0, 0.0}, Y = {0.0, 0.0, 0.0, 0.0};
         P = mma<0>(lda_rowmajor(TBLK(i, j), TS, li, lg), ldb_rowmajor(Dinv + j * DBLK, DS, li, lg), P);
         Y = mma<1>(lda_rowmajor(Dinv + i * DBLK, DS, li, lg), acc_as_b(P), Y);
         st_transposed(TBLK(j, i), TS, li, lg, Y);
-    }
+    };
+    if (wave == 0) inv16(T, Dinv, 7, lane);
+    else if (wave < 4) level1(2 * (wave - 1));
+    else store_factor_column(At, lda, T, 7, tid - 256, 256);
+    __syncthreads();
+    STAMP(27);
+    store_inverse_level<0>(Iv, T, Dinv, tid);
+    if (wave == 0) level1(6);
     __syncthreads();
     STAMP(28);
     store_inverse_level<1>(Iv, T, Dinv, tid);
@@ -456,7 +481,9 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
 __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, int t, double *invL, int *info) {
     __shared__ __attribute__((aligned(16))) double T[GP_TILE * TS];
     __shared__ __attribute__((aligned(16))) double Dinv[8 * DBLK];
-    potrf_tile_body(A, lda, t, invL, info, T, Dinv);
+    __shared__ __attribute__((aligned(16))) double zrow[16];   // the row of zeros E's idle lanes read
+    if (threadIdx.x < 16) zrow[threadIdx.x] = 0.0;             // (visible after the first barrier of the body)
+    potrf_tile_body(A, lda, t, invL, info, T, Dinv, zrow);
 }
 
 void launch_potrf_tile(hipStream_t s, double *A, long lda, int t, double *invL, int *info) {

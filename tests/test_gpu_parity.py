@@ -197,8 +197,16 @@ def test_stress_case_against_extended_precision_truth(golden, h, tag):
         e_hip = float(np.max(np.abs(np.asarray(hip, dtype=float) - truth))) / scale
         e_ref = float(np.max(np.abs(np.asarray(ref, dtype=float) - truth))) / scale
         report[name] = {"hip": e_hip, "lapack_reference": e_ref, "north_star_tol": tol}
-        if not e_hip <= max(tol, 4.0 * e_ref):
+        # two conditions: not worse than 4x LAPACK's own error where LAPACK itself misses the north-star tolerance, AND an
+        # absolute ceiling per quantity whatever LAPACK does -- the north-star tolerance itself for every quantity but d(LCB)/dx,
+        # where the reference's own float64 result is 6e-6 off the truth (measured worst cases over the 40 cases, both arithmetic
+        # modes: profiles/r03_stress_truth.json; the largest is alpha at 5e-8)
+        ceiling = {"neg_dLCB": 3e-5}.get(name, tol)
+        if not (e_hip <= max(tol, 4.0 * e_ref) and e_hip <= ceiling):
             bad.append((name, e_hip, e_ref))
+    for key, rec in recorded.items():   # EI / MPI ~11 sigma out in the tail: recorded above, with a loose backstop (measured 8e-5)
+        if not rec["hip"] <= 1e-3:
+            bad.append((key, rec["hip"], rec["lapack_reference"]))
     try:
         out = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
         os.makedirs(out, exist_ok=True)

@@ -163,3 +163,32 @@ def test_optimize_same_x0_same_lbfgs_matches_oracle_objective(monkeypatch, mode,
     assert abs(m2.log_likelihood() + f_or_end) <= 1e-4 * abs(f_or_end)
     m.close()
     m2.close()
+
+
+def test_bench_starts_its_own_ranks_on_one_device():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command): the parent spawns two
+    fresh rank processes, they rendezvous over 127.0.0.1, shard ONE candidate table (C4, reduced: N = 2048, 20 000 candidates),
+    exchange (best value, global row) pairs and print ONE JSON line from rank 0.  Both ranks sit on device 0 here
+    (GPHIP_BENCH_SAME_DEVICE: a one-GPU box), where RCCL refuses the duplicate device and the exchange is labelled gloo; on an
+    8-GPU node the only difference is the device index."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPHIP_EMULATE_FP64")}
+    env["GPHIP_BENCH_SAME_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--N", "2048", "--M", "20000",
+                          "--steps", "2", "--warmup", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"
+    assert "launch_ranks" in cfg["launcher"]
+    assert cfg["ranks_agree_on_winner"] is True
+    assert cfg["best_row_matches_single_gpu"] is True
+    assert cfg["candidates_total"] == 20000 and cfg["candidates_this_rank"] == 10000
+    assert {r["rank"] for r in cfg["rank_records"]} == {0, 1}
+    assert cfg["collective"].startswith("gloo") or cfg["rccl_comm_ranks"] == 2

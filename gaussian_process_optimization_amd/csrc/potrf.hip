@@ -19,7 +19,8 @@
 //         then a product per row block).  Columns are scaled by 1/sqrt(d_j) afterwards, all at once.
 //   Uc(p) the 16-column block column p+1 takes panel p's rank-16 update on the matrix pipe (one block per wave, 4 MFMAs):
 //         all that E(p+1) waits for.
-//   Ur(p) every other trailing block takes it WHILE E(p+1) runs, on the waves that do not eliminate.
+//   Ul(p) WHILE E(p) runs, on waves that do not eliminate, block column p+1 takes the updates of the panels 0 .. p-1 (left-
+//         looking for everything off the chain).
 //  Inverse by 2 x 2 block recursion, Inv[J][I] = -Inv[J][J] L[J][I] Inv[I][I]: the eight 16 x 16 diagonal inverses by
 //  substitution (seven of them beside E(4) .. E(7), the last beside the first level); then levels of 32, 64 and 128 rows, each as two rounds of independent block
 //  products spread evenly over the eight waves (the intermediate L[J][I] Inv[I][I] overwrites L[J][I] in LDS: the factor
@@ -120,6 +121,12 @@ __device__ __forceinline__ int eliminate_panel(double *T, const double *zero, in
                 if (j0 + u < 16) a[j0 + u] = fma(-m, s[u], a[j0 + u]);
         }
     }
+    // (What bounds these 16 steps is the pivot-to-pivot chain -- update of column k+1, v_readlane, reciprocal seed, its
+    // correction, the multiplier: six dependent f64 operations at ~22 cycles each, 2.1k cycles per micro panel -- not the
+    // instruction count: a version with the column updates as v_fmac_f64_dpp row_newbcast (one instruction per (j, k) instead of
+    // three, the diagonal block's column copied to every 16-lane row by ds_bpermute), software-pipelined and with a third-order
+    // reciprocal correction, was correct and 0.1k cycles faster per micro panel; without any column update at all the steps
+    // still take 3.0k.  The plain form stays.)
     const unsigned long long bad = __ballot(!(piv > 0.0)) & 0xFFFFull;
     const int fail = bad ? (int)__builtin_ctzll(bad) : -1;
     double sq, rs;
@@ -154,6 +161,27 @@ __device__ __forceinline__ void update_block(double *T, int p, int i, int j, int
     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc2, 0, 0, 1);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 1);
     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc2, 0, 0, 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cp[(4 * r) * TS] = acc[r] + acc2[r];
+}
+
+// block (i, c) -= sum over the solved micro panels 0 .. np-1 of X_i X_c^T (left-looking: one read and one write of the block for
+// np rank-16 updates; two accumulation chains)
+__device__ __forceinline__ void update_block_panels(double *T, int np, int i, int c, int li, int lg) {
+    const double *ap = T + (i * 16 + li) * TS + lg;
+    const double *bp = T + (c * 16 + li) * TS + lg;
+    double *cp = T + (i * 16 + lg) * TS + c * 16 + li;
+    double4_t acc, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = cp[(4 * r) * TS];
+    for (int q = 0; q < np; ++q) {
+        const double a0 = ap[q * 16], a1 = ap[q * 16 + 4], a2 = ap[q * 16 + 8], a3 = ap[q * 16 + 12];
+        const double b0 = bp[q * 16], b1 = bp[q * 16 + 4], b2 = bp[q * 16 + 8], b3 = bp[q * 16 + 12];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 1);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc2, 0, 0, 1);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 1);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc2, 0, 0, 1);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) cp[(4 * r) * TS] = acc[r] + acc2[r];
 }
@@ -346,21 +374,18 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
     for (int p = 0; p < 8; ++p) {
         STAMP(2 + 3 * p);
         if (p >= 1) {
-            // phase 1:  E(p) on waves 0 .. nE-1  ||  on the others Ur(p-1) (blocks (i, j), p+1 <= j <= i, with panel p-1) and
-            //           the factor's finished block column p-1 on its way to HBM
+            // phase 1:  E(p) on waves 0 .. nE-1  ||  on the others: block column p+1 takes the updates of ALL earlier panels
+            //           0 .. p-1 (left-looking: a trailing block is read and written once per micro panel it waits for, and the
+            //           work per window is even -- (7-p) 4p matrix instructions -- instead of the 84, 60, 40, ... of applying
+            //           panel p-1 to every trailing block at once), and the factor's finished block column p-1 leaves for HBM
             const int nrows = 7 - p;
             const int nE = nrows > 0 ? (nrows + 2) / 3 : 1;     // 2, 2, 2, 1, 1, 1, 1 for p = 1 .. 7
             // The eliminating waves are bound by their own instruction issue: the waves that share their SIMDs (wave w + 4 sits
             // on the SIMD of wave w) stay idle, the other 8 - 2 nE do the side work.  Worker index of a wave: its rank among
             // them, or -1.
-            // (while 15 or more trailing blocks are waiting, p <= 2, every free wave is needed and the partners work too)
-            int worker = -1, nworkers = 8 - nE;
-            if (p <= 2) {
-                if (wave >= nE) worker = wave - nE;
-            } else {
-                nworkers = 8 - 2 * nE;
-                if (wave >= nE && !(wave >= 4 && wave < 4 + nE)) worker = wave < 4 ? wave - nE : wave - 2 * nE;
-            }
+            int worker = -1;
+            const int nworkers = 8 - 2 * nE;
+            if (wave >= nE && !(wave >= 4 && wave < 4 + nE)) worker = wave < 4 ? wave - nE : wave - 2 * nE;
             if (wave < nE) {
                 __builtin_amdgcn_s_setprio(3);
                 const int rb0 = p + 1 + 3 * wave;
@@ -369,16 +394,11 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
                 if (wave == 0 && fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + p * 16 + fail + 1);
                 __builtin_amdgcn_s_setprio(0);
             } else if (worker >= 0) {
-                const int cnt = nrows * (nrows + 1) / 2;
-                for (int e = worker; e < cnt; e += nworkers) {
-                    int ii = 0;
-                    while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
-                    const int jj = e - ii * (ii + 1) / 2;
-                    update_block(T, p - 1, p + 1 + ii, p + 1 + jj, li, lg);
-                }
+                for (int i = p + 1 + worker; i < 8; i += nworkers) update_block_panels(T, p, i, p + 1, li, lg);
                 store_factor_column(At, lda, T, p - 1, worker * 64 + lane, nworkers * 64);
-                // the diagonal micro blocks 0..6 are inverted here, two per window from micro panel 4 on (few trailing blocks
-                // are left by then; more than two substitutions at a time are bound by their LDS broadcast reads)
+                // the diagonal micro blocks 0..6 are inverted here, two per window from micro panel 4 on (six workers and few
+                // blocks by then; more than two substitutions at a time are bound by their LDS broadcast reads, and on the
+                // eliminating wave's SIMD partner one takes 5k cycles at its low priority)
                 if (p >= 4 && worker >= 4) {
                     const int blk = 2 * (p - 4) + (worker - 4);
                     if (blk < 7) inv16(T, Dinv, blk, lane);

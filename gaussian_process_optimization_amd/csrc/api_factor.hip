@@ -68,13 +68,18 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
     hipStreamWaitEvent(sp, e0, 0);
     hipStreamWaitEvent(sb, e0, 0);
     const long PB = (long)W * GP_TILE;
+    const int nJu = (nt + W - 1) / W;
+    // Every inverted diagonal panel (alpha, the candidate solve and Ky^-1 all need them) is built on the side stream as soon
+    // as its panel of L is final, beside the rest of the factorisation: after the join nothing is left to build (as a pass of
+    // its own, 2W - 1 short launches in series, it held the main stream for 0.3 ms between the factor and its first consumer).
+    if ((rc = dev_realloc(&g->dInvP, &g->capInvP, (long)nJu * PB * PB))) return rc;
+    if ((rc = dev_realloc(&g->dInvPw, &g->capInvPw, (long)nJu * PB * PB))) return rc;
+    hipStreamWaitEvent(g->s_inv, e0, 0);
     if (pp.on) {
-        hipStreamWaitEvent(g->s_inv, e0, 0);
         hipStreamWaitEvent(g->s_pred, e0, 0);
         if (pp.init) pp.init(g->s_pred);
     }
     int next_pred = 0;
-    const int nJu = (nt + W - 1) / W;
     // Only the first `pipe_stages` candidate stages ride behind the factorisation (on the CU-masked stream, released
     // at panel pred_start); the caller runs the rest on the main stream, on every CU, once the factor is complete.
     const int pstages = pp.on ? std::max(1, std::min(nJu, pp.stages)) : 0;
@@ -117,12 +122,10 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
         hipEvent_t eF = la_event(g, EV_CHAIN, J);
         hipEventRecord(eF, sp);
         const int K = (J1 - J0) * GP_TILE;
+        hipStreamWaitEvent(g->s_inv, eF, 0);
+        build_panel_inv_one(g, g->s_inv, J, W, nt);
         if (pp.on) {
-            if (J < pstages) {
-                hipStreamWaitEvent(g->s_inv, eF, 0);
-                build_panel_inv_one(g, g->s_inv, J, W, nt);
-                hipEventRecord(la_event(g, EV_INVP, J), g->s_inv);
-            }
+            if (J < pstages) hipEventRecord(la_event(g, EV_INVP, J), g->s_inv);
             // Two concurrent MFMA-bound launches run slower than one after the other (measured 51 vs 63 TFLOP/s), and
             // the candidate stream is CU-masked like the trailing update (the diagonal-tile workgroup needs an empty
             // CU), which costs it 1/8 of the chip.  So only the first `pipe_stages` stages ride here, released once
@@ -240,12 +243,15 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
     }
     g->pipe_done = pstages;
     if (pp.on) {
-        hipEvent_t eq = la_event(g, EV_MISC, 3), ei = la_event(g, EV_MISC, 4);
+        hipEvent_t eq = la_event(g, EV_MISC, 3);
         hipEventRecord(eq, g->s_pred);
-        hipEventRecord(ei, g->s_inv);
         hipStreamWaitEvent(g->s, eq, 0);
-        hipStreamWaitEvent(g->s, ei, 0);
     }
+    hipEvent_t ei = la_event(g, EV_MISC, 4);
+    hipEventRecord(ei, g->s_inv);
+    hipStreamWaitEvent(g->s, ei, 0);
+    g->invp_W = W;
+    g->invp_valid = true;   // (fit_impl drops it again when the attempt turns out not positive definite)
     return la_events_ok(g);   // (an error return makes fit_impl quiesce every stream before it reports)
 }
 
@@ -366,10 +372,12 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
                 g->emu_off_call = true;
                 ++g->emu_fallbacks;
                 g->nphases = 0;
+                g->invp_valid = false;
                 continue;
             }
         }
         if (info == 0) break;
+        g->invp_valid = false;
         // jitter ladder, GPy/GPy/util/linalg.py:62-75
         if (!(diag0 > 0.0)) return fail(GP_ERR_NOT_PD_DIAG, "not pd: non-positive diagonal elements");
         if (tries == 0)
@@ -395,22 +403,21 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     if (pipe) {
         const int W = std::min(g->panel_tiles, nt_);
         const int nJ = (nt_ + W - 1) / W;
-        if (g->pipe_done >= nJ) {  // every inverted panel was built by the pipeline
-            g->invp_W = W;
-            g->invp_valid = true;
-        } else {  // the remaining stages on the main stream, every CU
+        if (g->pipe_done < nJ) {  // the remaining stages on the main stream, every CU
             int phr = phase_begin(g, pipe == 2 ? "potri_solve_rest" : "cand_solve_rest", 0.0, 0.0);
             int rci = ensure_panel_inv(g);
             if (rci) return rci;
+            hipEvent_t eI = la_event(g, EV_MISC, 5);
+            if (g->s_inv && g->side_alpha) hipEventRecord(eI, g->s);
+            // the long launches first: the 45 short launches of alpha / log det take the host 0.7 ms to enqueue, during which
+            // the main stream sat empty when they went first
+            solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), pipe == 2 ? 1 : 0, g->pipe_done);
             if (g->s_inv && g->side_alpha) {
-                hipEvent_t eI = la_event(g, EV_MISC, 5);
-                hipEventRecord(eI, g->s);
                 hipStreamWaitEvent(g->s_inv, eI, 0);
                 alpha_lml(g->s_inv);
                 hipEventRecord(la_event(g, EV_MISC, 6), g->s_inv);
                 side_alpha = true;
             }
-            solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), pipe == 2 ? 1 : 0, g->pipe_done);
             phase_end(g, phr);
         }
         if (pipe == 2) {

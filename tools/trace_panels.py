@@ -32,7 +32,11 @@ if len(sys.argv) > 3:
     for j in [int(x) for x in sys.argv[3].split(",")]:
         print("--- chain kernels of panel", j)
         prev = None
-        for r in panels[j]:
+        allq = len(sys.argv) > 4 and sys.argv[4] == "all"   # every queue's launches inside the panel's window
+        lo, hi = S(panels[j][0]), E(panels[j][-1])
+        sel = sorted([r for r in last if S(r) < hi and E(r) > lo], key=S) if allq else panels[j]
+        for r in sel:
+            if allq: print("  q%-3s" % r["Queue_Id"], end="")
             gap = 0.0 if prev is None else S(r) - prev
             prev = E(r)
             print("  %9.1f %9.1f dur %7.1f gap %6.1f wg %6d x %s %s" % (S(r), E(r), E(r) - S(r), gap,

@@ -505,7 +505,12 @@ def main():
                          "avg_launch_ms": gs["ms"] / max(gs["launches"], 1),
                          "busy_ms_total": busy_ms, "achieved_while_running": gs["flops"] / max(busy_ms, 1e-9) / 1e9,
                          "frac_while_running": gs["flops"] / max(busy_ms, 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS,
-                         "flops_per_launch_avg": gs["flops"] / max(gs["launches"], 1)},
+                         "flops_per_launch_avg": gs["flops"] / max(gs["launches"], 1),
+                         # the whole step against the same peak: N^3/3 (Cholesky) + N^2 M (candidate solve) algorithmic flops of
+                         # ONE rank's step / ms_per_step -- K builds, chain, reductions and launch gaps all inside the time
+                         "step_algorithmic_flops": N ** 3 / 3.0 + float(N) * N * M,
+                         "step_achieved": (N ** 3 / 3.0 + float(N) * N * M) / (ms_per_step * 1e-3) / 1e12,
+                         "step_frac": (N ** 3 / 3.0 + float(N) * N * M) / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
             "chain_gemm": {"bound": "mfma", "kernel": "gemm_nt_kernel<1, 64, 2, false, 64> (the same C -= A B^T as 64 x 64 work "
                                                       "units: the factorisation chain's in-panel / look-ahead updates)",
                            "launches_per_step": cs["launches"], "kernel_ms_per_step": cs["ms"],

@@ -192,3 +192,39 @@ def test_bench_starts_its_own_ranks_on_one_device():
     assert cfg["candidates_total"] == 20000 and cfg["candidates_this_rank"] == 10000
     assert {r["rank"] for r in cfg["rank_records"]} == {0, 1}
     assert cfg["collective"].startswith("gloo") or cfg["rccl_comm_ranks"] == 2
+
+
+def test_bench_line_keeps_the_driver_contract():
+    """One short `python bench.py` (N = 1, the quoted workload, two timed steps, CPU baseline and the emulated line switched off
+    to stay within seconds): ONE JSON line with the keys the driver reads, the metric of BASELINE.json, true fp64, and the roofline
+    entry for the dominant kernel measured inside the timed region -- per launch and for the whole step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-emulated-line"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"] in base["metric"]
+    for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["emulate_fp64"] == 0
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-9
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
+    assert r["launches"] > 0 and r["avg_launch_ms"] > 0
+    # the whole step: N^3/3 + N^2 M algorithmic flops over the measured step time
+    N, M = 16384, 10000
+    assert abs(r["step_algorithmic_flops"] - (N ** 3 / 3.0 + float(N) * N * M)) < 1.0
+    assert abs(r["step_achieved"] - r["step_algorithmic_flops"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-9
+    assert 0.3 < r["step_frac"] < 1.0

@@ -6,9 +6,16 @@
 
 // ---- blocked right-looking Cholesky (two-level: 128-column steps inside panel_tiles-wide panels) ----
 // A: nt x nt tiles (lower) plus R1 - nt extra row tiles that ride through the panel solves and updates (the RHS rows)
-void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, int *info) {
+// side_inv (the model's own factor only): the inverted diagonal panel of each panel is built on the side stream as soon as that
+// panel's columns are final, beside the trailing update and the next panel -- one event record per panel on this stream.
+void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, int *info, bool side_inv) {
     const int W = g->panel_tiles;
     hipStream_t s = g->s;
+    if (side_inv) {
+        hipEvent_t e0 = la_event(g, EV_MISC, 0);
+        hipEventRecord(e0, s);
+        hipStreamWaitEvent(g->s_inv, e0, 0);
+    }
     for (int J0 = 0; J0 < nt; J0 += W) {
         const int J1 = std::min(J0 + W, nt);
         for (int j = J0; j < J1; ++j) {
@@ -21,16 +28,45 @@ void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, in
                 gemm(g, s, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE,
                      TileSet{0, R1, j + 1, J1, 1});
         }
+        if (side_inv) {
+            hipEvent_t eF = la_event(g, EV_CHAIN, J0 / W);
+            hipEventRecord(eF, s);
+            hipStreamWaitEvent(g->s_inv, eF, 0);
+            build_panel_inv_one(g, g->s_inv, J0 / W, W, nt);
+        }
         // trailing update with the whole panel (K = W * 128): the dense contraction on MFMA
         if (J1 < nt)
             gemm(g, s, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, (J1 - J0) * GP_TILE,
                  TileSet{0, R1, J1, nt, 1});
     }
+    if (side_inv) {
+        hipEvent_t ei = la_event(g, EV_MISC, 4);
+        hipEventRecord(ei, g->s_inv);
+        hipStreamWaitEvent(s, ei, 0);
+    }
 }
 
-void factor(gp_ctx *g) {
+// The single-stream factorisation of the model's Ky (N <= 768, and the sizes where the look-ahead's per-panel events, waits and
+// separate look-ahead launch cost more than the overlap gives: measured 1.99 vs 2.31 ms at N = 4096, 0.84 vs 1.05 at N = 2048,
+// equal from N = 5120 on; same arithmetic, bitwise the same factor).  Panels wider than the matrix take the batched inverse build.
+int factor(gp_ctx *g) {
     const int nt = (int)(g->Npad / GP_TILE);
-    factor_buf(g, g->dA, g->Npad, nt, nt + 1, g->dInvL, g->dInfo);
+    const int W = g->panel_tiles;
+    const bool side = nt > W && g->s_inv;
+    if (side) {
+        const long PB = (long)W * GP_TILE;
+        const int nJ = (nt + W - 1) / W;
+        int rc;
+        if ((rc = dev_realloc(&g->dInvP, &g->capInvP, (long)nJ * PB * PB))) return rc;
+        if ((rc = dev_realloc(&g->dInvPw, &g->capInvPw, (long)nJ * PB * PB))) return rc;
+    }
+    factor_buf(g, g->dA, g->Npad, nt, nt + 1, g->dInvL, g->dInfo, side);
+    if (side) {
+        g->invp_W = W;
+        g->invp_valid = true;   // (fit_impl drops it again when the attempt turns out not positive definite)
+        return la_events_ok(g);
+    }
+    return 0;
 }
 
 void build_panel_inv_one(gp_ctx *g, hipStream_t s, int J, int W, int nt) {
@@ -94,7 +130,7 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
     // (rns.hip).  The Schur complement right of the look-ahead panel lives as Ky (untouched, in dA) minus an exact integer
     // accumulator dRm; a panel's columns are rebuilt in fp64 once, right before they become the look-ahead target.  The
     // chain (diagonal tiles, panel solves, in-panel and look-ahead updates) and the right-hand-side tile row stay fp64.
-    const bool emu = g->emulate_fp64 && g->emulate_fit && !g->emu_off_call && (PB % 256 == 0) && PB <= GP_RNS_KMAX;
+    const bool emu = emu_fit_applies(g);
     RnsGeom rg;
     int *rflag = g->dInfo + 2;
     if (emu) {
@@ -353,11 +389,13 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
             if (rcf) return rcf;
         } else {
             ph = phase_begin(g, "cholesky", (double)N * N * N / 3.0, 0.0);
-            if (g->lookahead && Npad / GP_TILE > g->panel_tiles) {
+            // (the emulated trailing update lives in the look-ahead scheduler)
+            if (g->lookahead && nt_ > g->panel_tiles && (nt_ > g->lookahead_min_tiles || emu_fit_applies(g))) {
                 int rcf = factor_lookahead(g);
                 if (rcf) return rcf;
             } else {
-                factor(g);
+                int rcf = factor(g);
+                if (rcf) return rcf;
             }
         }
         phase_end(g, ph);

@@ -113,6 +113,7 @@ struct gp_ctx {
     // options
     int panel_tiles = 6;
     int lookahead = 1;
+    int lookahead_min_tiles = 40;   // gp_fit: matrices of at most this many tiles (N <= 5120) take the single-stream factorisation
     int reserve_cus = 32;
     long mc_max = 16384;
     // profiling
@@ -172,6 +173,12 @@ struct gp_ctx {
 };
 
 static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+
+// the factorisation's trailing update runs in residue form (option emulate_fp64 with emulate_fit; panel edges on 256-column blocks)
+static inline bool emu_fit_applies(const gp_ctx *g) {
+    const long PB = (long)g->panel_tiles * GP_TILE;
+    return g->emulate_fp64 && g->emulate_fit && !g->emu_off_call && (PB % 256 == 0) && PB <= GP_RNS_KMAX;
+}
 
 static inline GemmOpt inplace_opt() {
     GemmOpt o;
@@ -240,8 +247,8 @@ void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const double 
 void rns_gemm(gp_ctx *g, hipStream_t s, const signed char *A, long lda, long a_plane, const signed char *B, long ldb, long b_plane, signed char *R, int mt_all, int nt_all, int mt, int c0, int c1, int K, int first, int tri = 0);
 int dev_realloc(double **p, long *cap, long need);
 void destroy_ctx_events(gp_ctx *g);
-void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, int *info);
-void factor(gp_ctx *g);
+void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, int *info, bool side_inv = false);
+int factor(gp_ctx *g);
 void build_panel_inv_one(gp_ctx *g, hipStream_t s, int J, int W, int nt);
 int byte_realloc(signed char **p, long *cap, long need);
 int rns_prepare(gp_ctx *g, double jitter, RnsGeom *r);

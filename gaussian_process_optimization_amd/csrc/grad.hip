@@ -27,12 +27,12 @@ __device__ __forceinline__ double wave_sum_g(double v) {
 // k(r) and g(r) = dK_dr(r) / r (finite at r = 0 for both kernels)
 __device__ __forceinline__ void k_and_g(int kernel, double variance, double r2, double &k, double &g) {
     if (kernel == 0) {
-        k = variance * exp(-0.5 * r2);
+        k = variance * gp_exp_nonpos(-0.5 * r2);
         g = -k;  // dK_dr = -r k
     } else {
         const double s5 = 2.23606797749978969640917366873128;
         const double r = sqrt(r2);
-        const double e = exp(-s5 * r);
+        const double e = gp_exp_nonpos(-s5 * r);
         k = variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * e;
         g = -(5.0 / 3.0) * variance * (1.0 + s5 * r) * e;  // (10/3 r - 5 r - 5 sqrt5/3 r^2) e / r
     }

@@ -17,11 +17,11 @@
 
 __device__ __forceinline__ double k_of_r2(int kernel, double variance, double r2) {
     if (kernel == 0) {
-        return variance * exp(-0.5 * r2);
+        return variance * gp_exp_nonpos(-0.5 * r2);
     } else {
         const double s5 = 2.23606797749978969640917366873128;  // sqrt(5)
         const double r = sqrt(r2);
-        return variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * exp(-s5 * r);
+        return variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * gp_exp_nonpos(-s5 * r);
     }
 }
 // one 1-D factor of the Gower product kernel: K_of_r(|dx|) for a continuous dimension (dx already divided by
@@ -41,12 +41,16 @@ __device__ __forceinline__ void stage_rows_T(double *dst, const double *X, long 
     }
 }
 
+// DU > 0: the dimension loop unrolled to DU (LDS rows D .. DU-1 are staged as zeros), the thread's two columns held in registers
+// across its 32 rows; DU = 0: run-time loop (D > 16, and the Gower product kernel).
 // grid: lower tiles enumerated row-wise (tm >= tn): t = tm(tm+1)/2 + tn
+template <int DU>
 __global__ __launch_bounds__(256) void kbuild_kernel(double *A, long lda, const double *X, long N, long Npad,
                                                      KernParams kp, double diag_add, int full, int nt) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *xi = sm;                          // [D][128]
-    double *xj = sm + (long)kp.D * GP_TILE;   // [D][128]
+    const int DS = DU > 0 ? DU : kp.D;        // staged dimensions
+    double *xi = sm;                          // [DS][128]
+    double *xj = sm + (long)DS * GP_TILE;     // [DS][128]
     __shared__ double ils[GP_MAX_D];
     const int tid = threadIdx.x;
     int tm, tn;
@@ -64,11 +68,18 @@ __global__ __launch_bounds__(256) void kbuild_kernel(double *A, long lda, const 
     __syncthreads();
     stage_rows_T(xi, X, (long)tm * GP_TILE, N, kp.D, ils, tid);
     stage_rows_T(xj, X, (long)tn * GP_TILE, N, kp.D, ils, tid);
+    if (DU > 0)
+        for (int idx = kp.D * GP_TILE + tid; idx < DU * GP_TILE; idx += 256) xi[idx] = xj[idx] = 0.0;
     __syncthreads();
 
     const int cx = (tid & 63) * 2;   // two columns
     const int ry = tid >> 6;         // rows ry + 4q
     const long gc = (long)tn * GP_TILE + cx;
+    double2_t bq[DU > 0 ? DU : 1];
+    if (DU > 0) {
+#pragma unroll
+        for (int d = 0; d < DU; ++d) bq[d] = *(const double2_t *)(xj + d * GP_TILE + cx);
+    }
     for (int q = 0; q < 32; ++q) {
         const int r = ry + 4 * q;
         const long gr = (long)tm * GP_TILE + r;
@@ -85,12 +96,22 @@ __global__ __launch_bounds__(256) void kbuild_kernel(double *A, long lda, const 
             out[1] = p1;
         } else {
             double s0 = 0.0, s1 = 0.0;
-            for (int d = 0; d < kp.D; ++d) {
-                const double a = xi[d * GP_TILE + r];
-                const double2_t b = *(const double2_t *)(xj + d * GP_TILE + cx);
-                const double d0 = a - b[0], d1 = a - b[1];
-                s0 = fma(d0, d0, s0);
-                s1 = fma(d1, d1, s1);
+            if (DU > 0) {
+#pragma unroll
+                for (int d = 0; d < DU; ++d) {
+                    const double a = xi[d * GP_TILE + r];
+                    const double d0 = a - bq[d][0], d1 = a - bq[d][1];
+                    s0 = fma(d0, d0, s0);
+                    s1 = fma(d1, d1, s1);
+                }
+            } else {
+                for (int d = 0; d < kp.D; ++d) {
+                    const double a = xi[d * GP_TILE + r];
+                    const double2_t b = *(const double2_t *)(xj + d * GP_TILE + cx);
+                    const double d0 = a - b[0], d1 = a - b[1];
+                    s0 = fma(d0, d0, s0);
+                    s1 = fma(d1, d1, s1);
+                }
             }
             out[0] = k_of_r2(kp.kernel, kp.variance, s0);
             out[1] = k_of_r2(kp.kernel, kp.variance, s1);
@@ -115,9 +136,14 @@ void launch_kbuild(hipStream_t s, double *A, long lda, const double *X, long N, 
                    const KernParams &kp, double diag_add, int full) {
     const int nt = (int)(Npad / GP_TILE);
     const long nblk = full ? (long)nt * nt : (long)nt * (nt + 1) / 2;
-    const size_t shm = (size_t)2 * kp.D * GP_TILE * sizeof(double);
-    hipLaunchKernelGGL(kbuild_kernel, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp,
-                       diag_add, full, nt);
+    const int DU = kp.gower ? 0 : (kp.D <= 8 ? 8 : (kp.D <= 16 ? 16 : 0));
+    const size_t shm = (size_t)2 * (DU ? DU : kp.D) * GP_TILE * sizeof(double);
+    if (DU == 8)
+        hipLaunchKernelGGL(kbuild_kernel<8>, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp, diag_add, full, nt);
+    else if (DU == 16)
+        hipLaunchKernelGGL(kbuild_kernel<16>, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp, diag_add, full, nt);
+    else
+        hipLaunchKernelGGL(kbuild_kernel<0>, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp, diag_add, full, nt);
 }
 
 __global__ void set_rhs_kernel(double *A, long lda, const double *Y, long N, long Npad, int P) {
@@ -133,11 +159,13 @@ void launch_set_rhs(hipStream_t s, double *A, long lda, const double *Y, long N,
 }
 
 // T[c][i] = k(xs_c, x_i); tiles (tc over candidates, ti over training points)
+template <int DU>
 __global__ __launch_bounds__(256) void cross_k_kernel(double *T, long ldt, const double *Xs, long M, const double *X,
                                                       long N, KernParams kp, int nti) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int DS = DU > 0 ? DU : kp.D;
     double *xc = sm;
-    double *xt = sm + (long)kp.D * GP_TILE;
+    double *xt = sm + (long)DS * GP_TILE;
     __shared__ double ils[GP_MAX_D];
     const int tid = threadIdx.x;
     const int tc = blockIdx.x / nti, ti = blockIdx.x % nti;
@@ -145,10 +173,17 @@ __global__ __launch_bounds__(256) void cross_k_kernel(double *T, long ldt, const
     __syncthreads();
     stage_rows_T(xc, Xs, (long)tc * GP_TILE, M, kp.D, ils, tid);
     stage_rows_T(xt, X, (long)ti * GP_TILE, N, kp.D, ils, tid);
+    if (DU > 0)
+        for (int idx = kp.D * GP_TILE + tid; idx < DU * GP_TILE; idx += 256) xc[idx] = xt[idx] = 0.0;
     __syncthreads();
     const int cx = (tid & 63) * 2;
     const int ry = tid >> 6;
     const long gi = (long)ti * GP_TILE + cx;
+    double2_t bq[DU > 0 ? DU : 1];
+    if (DU > 0) {
+#pragma unroll
+        for (int d = 0; d < DU; ++d) bq[d] = *(const double2_t *)(xt + d * GP_TILE + cx);
+    }
     for (int q = 0; q < 32; ++q) {
         const int r = ry + 4 * q;
         const long gcand = (long)tc * GP_TILE + r;
@@ -164,12 +199,22 @@ __global__ __launch_bounds__(256) void cross_k_kernel(double *T, long ldt, const
             }
         } else {
             double s0 = 0.0, s1 = 0.0;
-            for (int d = 0; d < kp.D; ++d) {
-                const double a = xc[d * GP_TILE + r];
-                const double2_t b = *(const double2_t *)(xt + d * GP_TILE + cx);
-                const double d0 = a - b[0], d1 = a - b[1];
-                s0 = fma(d0, d0, s0);
-                s1 = fma(d1, d1, s1);
+            if (DU > 0) {
+#pragma unroll
+                for (int d = 0; d < DU; ++d) {
+                    const double a = xc[d * GP_TILE + r];
+                    const double d0 = a - bq[d][0], d1 = a - bq[d][1];
+                    s0 = fma(d0, d0, s0);
+                    s1 = fma(d1, d1, s1);
+                }
+            } else {
+                for (int d = 0; d < kp.D; ++d) {
+                    const double a = xc[d * GP_TILE + r];
+                    const double2_t b = *(const double2_t *)(xt + d * GP_TILE + cx);
+                    const double d0 = a - b[0], d1 = a - b[1];
+                    s0 = fma(d0, d0, s0);
+                    s1 = fma(d1, d1, s1);
+                }
             }
             k0 = k_of_r2(kp.kernel, kp.variance, s0);
             k1 = k_of_r2(kp.kernel, kp.variance, s1);
@@ -184,7 +229,13 @@ __global__ __launch_bounds__(256) void cross_k_kernel(double *T, long ldt, const
 void launch_cross_k(hipStream_t s, double *T, long ldt, const double *Xs, long M, long Mpad, const double *X,
                     long N, long Npad, const KernParams &kp) {
     const int ntc = (int)(Mpad / GP_TILE), nti = (int)(Npad / GP_TILE);
-    const size_t shm = (size_t)2 * kp.D * GP_TILE * sizeof(double);
-    hipLaunchKernelGGL(cross_k_kernel, dim3((unsigned)((long)ntc * nti)), dim3(256), shm, s, T, ldt, Xs, M, X, N,
-                       kp, nti);
+    const int DU = kp.gower ? 0 : (kp.D <= 8 ? 8 : (kp.D <= 16 ? 16 : 0));
+    const size_t shm = (size_t)2 * (DU ? DU : kp.D) * GP_TILE * sizeof(double);
+    const dim3 grid((unsigned)((long)ntc * nti));
+    if (DU == 8)
+        hipLaunchKernelGGL(cross_k_kernel<8>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
+    else if (DU == 16)
+        hipLaunchKernelGGL(cross_k_kernel<16>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
+    else
+        hipLaunchKernelGGL(cross_k_kernel<0>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
 }

@@ -228,3 +228,33 @@ def test_bench_line_keeps_the_driver_contract():
     assert abs(r["step_algorithmic_flops"] - (N ** 3 / 3.0 + float(N) * N * M)) < 1.0
     assert abs(r["step_achieved"] - r["step_algorithmic_flops"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-9
     assert 0.3 < r["step_frac"] < 1.0
+
+
+@pytest.mark.parametrize("kname", ["rbf", "matern52"])
+def test_covariance_exponential_over_its_whole_argument_range(kname):
+    """The covariance builders evaluate exp with an in-house routine for non-positive arguments (csrc/gphip_internal.h).  One input
+    dimension, distances chosen so that the exponent runs from 0 down past the underflow threshold: relative error against
+    numpy's exp <= 4 ulp wherever the value is a normal number, exact zeros / subnormals beyond, NaN stays NaN."""
+    var, ell = 1.0, 1.0
+    # exponent values -a for a on a fine grid in [0, 760] plus the edges; RBF: -r^2 / 2, Matern-5/2: -sqrt(5) r
+    a = np.r_[np.linspace(0.0, 760.0, 4001), [1e-300, 1e-17, 0.5 * np.log(2.0), 708.0, 745.0, 745.2, 800.0, 1e6]]
+    r = np.sqrt(2.0 * a) if kname == "rbf" else a / np.sqrt(5.0)
+    X = np.zeros((1, 1))
+    X2 = r.reshape(-1, 1)
+    h = _lib.Handle(0)
+    h.set_data(X, np.zeros((1, 1)))
+    h.set_params(0 if kname == "rbf" else 1, 0, var, [ell], 0.1)
+    K = h.cross_kernel_matrix(X2)[0]
+    kern0 = (O.RBF if kname == "rbf" else O.Matern52)(1, var, ell)
+    K0 = kern0.K(X, X2)[0]
+    normal = K0 > 1e-300
+    assert np.max(np.abs(K[normal] - K0[normal]) / K0[normal]) <= 4 * 2.3e-16
+    assert np.all(K[~normal] >= 0.0) and np.all(K[~normal] <= 1e-299)
+    assert K[0] == var
+    Xn = np.array([[np.nan], [np.inf]])
+    Kn = h.cross_kernel_matrix(Xn)[0]
+    with np.errstate(invalid="ignore"):
+        K0n = kern0.K(X, Xn)[0]          # RBF: nan, 0;  Matern-5/2: nan, nan (inf * 0), as the reference's expression gives
+    assert np.array_equal(np.isnan(Kn), np.isnan(K0n)) and np.isnan(Kn[0])
+    assert np.array_equal(Kn[~np.isnan(Kn)], K0n[~np.isnan(K0n)])
+    h.close()

@@ -195,7 +195,7 @@ def static_traffic(N, D, M):
     """HBM-side traffic of the dominant kernel from the committed PMC passes of THIS command (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, tools/pmc_traffic.py).  Not measured by this run: carried with its
     provenance and dropped when gemm.hip has changed since the passes were taken."""
-    tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
     if not os.path.exists(tpath) or (N, D, M) != (16384, 8, 10000):
         return None, None
     with open(tpath) as f:
@@ -205,7 +205,7 @@ def static_traffic(N, D, M):
     if tj.get("gemm_hip_sha256_16") != sha:
         return None, {"static": True, "dropped": "gemm.hip changed since the counter passes (%s != %s)"
                                                  % (tj.get("gemm_hip_sha256_16"), sha)}
-    return tj["traffic_bytes_per_launch"], {"static": True, "file": "profiles/r02_gemm_traffic.json",
+    return tj["traffic_bytes_per_launch"], {"static": True, "file": "profiles/r03_gemm_traffic.json",
                                             "kernel": GEMM_SYMBOL, "launches": tj["launches"],
                                             "gemm_hip_sha256_16": sha,
                                             "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch")}
@@ -523,7 +523,7 @@ def main():
             "kbuild": {"bound": "hbm", "kernel": "kbuild_kernel (+ set_rhs_kernel: the 'kbuild' phase of gp_fit, HIP events)",
                        "algorithmic_bytes": kb["bytes"], "ms": kb["ms"], "achieved": kb_gbs, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": kb_gbs / HBM_PEAK_GBS,
-                       "counter_evidence": "profiles/r02_kbuild_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"},
+                       "counter_evidence": "profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"},
         }
         if emulated is not None:
             result["emulated_fp64_second_line"] = emulated

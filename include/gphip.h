@@ -251,6 +251,8 @@ int gp_synchronize(gp_t *gp);
 /* Tunables (none changes a result beyond rounding; tests/test_gpu_random_shapes.py sweeps the blocking ones):
  *   "panel_tiles"        outer panel width of the factorisation and of the inverted panels, in 128-tiles (default 6)
  *   "lookahead"          0/1: one panel of look-ahead on separate streams (default 1)
+ *   "lookahead_min_tiles"  gp_fit alone: matrices of at most this many 128-tiles (default 40, N <= 5120) take the same
+ *                        factorisation on ONE stream (bitwise the same factor; the look-ahead's per-panel events cost more there)
  *   "mc_max"             candidate rows per chunk (default 16384)
  *   "small_below", "chain_small_below"   launches with fewer 128-tiles run as 64x64 work units (1400 / 400 on the chain)
  *   "waves8", "stagger", "trsm_rows64", "supertile"   GEMM launch shape

@@ -1,6 +1,7 @@
 // Microbenchmarks (test tooling): fp64 MFMA issue rate, and the GEMM kernel alone on large tile sets.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "../../gaussian_process_optimization_amd/csrc/gphip_internal.h"
 
@@ -12,6 +13,31 @@ __global__ __launch_bounds__(256) void mfma_loop(double *out, int iters) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// the same loop with operands that differ from one MFMA to the next and carry random mantissas (what a GEMM on real data feeds
+// the pipe): the rate of the first loop is the issue rate at the clock the chip holds on near-constant operands, this one's is
+// the ceiling of any fp64 MFMA kernel on real data
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_loop_rand(double *out, int iters) {
+    double4_t acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (double4_t){0, 0, 0, 0};
+    double a[8], b[8];
+    unsigned long long h = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1 + 977u * blockIdx.x);
+    for (int i = 0; i < 8; ++i) {
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        a[i] = __longlong_as_double((long long)((h & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull)) - 1.5;
+        h ^= h >> 31; h *= 0x94D049BB133111EBull; h ^= h >> 29;
+        b[i] = __longlong_as_double((long long)((h & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull)) - 1.5;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i & 7]), "v"(b[(i * 3 + 1) & 7]));
     }
     double s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -36,6 +62,18 @@ int main() {
         printf("mfma f64 16x16x4, %d waves/SIMD: %.2f TFLOP/s (%.1f ms); cycles/MFMA/SIMD at 2.4GHz: %.1f\n", bpc, flops / ms / 1e9, ms,
                ms * 1e-3 * 2.4e9 / ((double)iters * 16 * bpc));
     }
+    for (int bpc : {1, 2}) {
+        const int blocks = 256 * bpc, iters = 20000;
+        hipLaunchKernelGGL(mfma_loop_rand<16>, dim3(blocks), dim3(256), 0, 0, out, 100);
+        CHK(hipDeviceSynchronize());
+        CHK(hipEventRecord(e0));
+        hipLaunchKernelGGL(mfma_loop_rand<16>, dim3(blocks), dim3(256), 0, 0, out, iters);
+        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        double flops = (double)blocks * 4 * iters * 16 * 2048.0;
+        printf("mfma f64 16x16x4, RANDOM operands changing every MFMA, %d waves/SIMD: %.2f TFLOP/s (%.1f ms)\n", bpc, flops / ms / 1e9, ms);
+    }
+    if (getenv("MFMA_PEAK_ONLY")) return 0;
     // GEMM alone
     const long N = 16384, lda = N;
     double *A, *C;

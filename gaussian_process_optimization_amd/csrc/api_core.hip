@@ -331,8 +331,8 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
         if (value < 0) return fail(GP_ERR_ARG, "lookahead_min_tiles < 0");
         g->lookahead_min_tiles = (int)std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "pipe_start_pct")) {
-        if (value < 0 || value > 100) return fail(GP_ERR_ARG, "pipe_start_pct out of range");
-        g->pipe_start_pct = (int)value;
+        if (value < -1 || value > 100) return fail(GP_ERR_ARG, "pipe_start_pct out of range");
+        g->pipe_start_pct = (int)value;   // -1: automatic
     } else if (!strcmp(name, "small_below")) {
         g->small_below = (int)value;
     } else if (!strcmp(name, "profile_min_tiles")) {

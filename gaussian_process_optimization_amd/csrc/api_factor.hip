@@ -349,7 +349,7 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         // 0 = automatic: the share of the panels that was best at N = 16384 (3 of 22 candidate stages, 8 of 22 L^-T stages)
         pp.stages = pipe == 2 ? (g->pipe_stages_grad > 0 ? g->pipe_stages_grad : std::max(1, (nJ * 36 + 50) / 100))
                               : (g->pipe_stages > 0 ? g->pipe_stages : std::max(1, (nJ * 14 + 50) / 100) + (nJ <= 12 ? 1 : 0));  // small N: the chain is everything
-        pp.start_pct = pipe == 2 ? g->pipe_start_pct_grad : g->pipe_start_pct;
+        pp.start_pct = pipe == 2 ? g->pipe_start_pct_grad : (g->pipe_start_pct >= 0 ? g->pipe_start_pct : (nJ <= 24 ? 32 : 40));
     }
     const double diag_add = g->noise + 1e-8;  // exact_gaussian_inference.py:56
     const double diag0 = (g->kp.gower ? std::pow(g->kp.variance, g->D) : g->kp.variance) + diag_add;

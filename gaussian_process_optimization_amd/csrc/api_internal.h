@@ -141,7 +141,7 @@ struct gp_ctx {
     int pipe_stages_grad = 0, pipe_start_pct_grad = 40;  // the same for gp_fit_grad (stages of the solve for L^-T)
     int pipe_stages = 0;         // gp_fit_predict: candidate stages that ride behind the factorisation (rest afterwards)
     int pipe_done = 0;           // ... how many did, in the last factorisation
-    int pipe_start_pct = 40;     // ... released once this share of the panels is factored (the chain sets the pace from there)
+    int pipe_start_pct = -1;     // ... released once this share of the panels is factored (the chain sets the pace from there); -1: 32 % up to 24 panels, 40 % beyond (measured N = 8192 ... 32768)
     std::vector<int> gemm_K;
     size_t gemm_ev_used = 0;
     long gemm_launches = 0;

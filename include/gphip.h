@@ -133,7 +133,7 @@ int gp_set_candidates(gp_t *gp, const double *Xs, int64_t M);
 int gp_predict(gp_t *gp, int include_noise, double *mean, double *var);
 
 /* gp_fit + gp_predict on the resident candidates as ONE call.  The first "pipe_stages" (3 at N = 16384) panel stages of
- * the candidate solve ride behind the factorisation once "pipe_start_pct" % (default 40) of its panels are done --
+ * the candidate solve ride behind the factorisation once "pipe_start_pct" % (default: 32 up to 24 panels, 40 beyond) of its panels are done --
  * from there the factorisation's latency chain leaves CUs idle -- and the rest run after it.  Bitwise the results of
  * the two calls in sequence; 5 % faster at N=16384, M=10^4 (BO.suggest_next_locations always runs the two back to
  * back: GPyOpt/GPyOpt/core/bo.py:236-254 then acquisitions/base.py:33-39). */
@@ -258,7 +258,7 @@ int gp_synchronize(gp_t *gp);
  *   "waves8", "stagger", "trsm_rows64", "supertile"   GEMM launch shape
  *   "pipe_stages", "pipe_start_pct"   gp_fit_predict: how many candidate stages ride behind the factorisation (0 = automatic:
  *                        14 % of the panels, 3 at N = 16384) and
- *                        after which share of its panels they are released (40)
+ *                        after which share of its panels they are released (-1 = automatic: 32 up to 24 panels, 40 beyond)
  *   "pipe_stages_grad", "pipe_start_pct_grad"   the same for gp_fit_grad (0 = automatic: 36 % of the panels; 40)
  *   "lauum_panels"       Ky^-1 product accumulated per k-panel (default 1)
  *   "pair_tri"           triangular-K products: column tiles paired for equal contraction length (default 2)

@@ -392,7 +392,7 @@ def test_fit_predict_pipelined_equals_separate_calls(h, N, M, pt, stages, start)
     assert relmax(m1, mo) < 1e-6 and np.max(np.abs(v1 - vo) / vo) < 1e-6
     h.set_option("panel_tiles", 6)
     h.set_option("pipe_stages", 0)
-    h.set_option("pipe_start_pct", 40)
+    h.set_option("pipe_start_pct", -1)
 
 
 def test_fit_predict_jitter_and_failure(golden, h):

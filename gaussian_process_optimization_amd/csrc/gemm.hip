@@ -17,8 +17,11 @@
 // Work decomposition: 256 threads = 4 waves as 2x2; each wave owns a 64x64 sub-tile =
 // 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  Per BK stage a wave issues 64 MFMAs
 // against 16 ds_read_b128, i.e. the matrix pipe is the only busy unit; the next stage's global
-// loads are issued before the MFMAs and written to the other LDS buffer after them (one
-// barrier per stage).  Two workgroups per CU (73.7 KB LDS each, <=256 VGPRs) keep a second
+// loads are issued before the MFMAs and written to the other LDS buffer BETWEEN the stage's two
+// halves, in front of the stage's one barrier: the second half's fragments are in registers by
+// then, so a wave released from the barrier issues MFMAs at once, and the fragments the first
+// MFMAs of a half need are read in the middle of the half before it (round 3: 65.9 -> 69.0
+// TFLOP/s for the kernel alone).  Two workgroups per CU (73.7 KB LDS each, <=256 VGPRs) keep a second
 // wave per SIMD ready while the first sits at the barrier or in the C epilogue.
 //
 // Roofline: algorithmic flops per launch = 2 * 128*128 * K * ntiles; bound = fp64 MFMA.
@@ -224,6 +227,28 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? (BM < BT ? 2 : NWN) : 4)) v
     const int aoff = (wm * WT + li) * LSTR + lg * 4;
     const int boff = BM * LSTR + (wn * WTN + li) * LSTR + lg * 4;
 
+    // Stage schedule: the fragments of the second half of a stage are read BEFORE the stage's barrier and its MFMAs issued after
+    // it, so that a wave released from the barrier has 16 MFMAs to issue at once (no LDS latency behind the barrier's skew); the
+    // first half of the next stage is read after them.  Every read of a buffer precedes the barrier in front of the stage that
+    // overwrites it.  Lane group lg owns k = 4lg..4lg+3 of the stage; MFMA step (h,e) contracts k = 4g + 2h + e over the four lane
+    // groups g, so two ds_read_b128 per operand row-tile feed four MFMA steps.
+    // Fragment registers: the second half of a stage multiplies af[0..MT) x bf[0..NT); the first half multiplies
+    // {pa, af[1..MT)} x pb[0..NT): the three fragments the first MFMAs of a half need (row tile 0, every column tile) are read
+    // in the MIDDLE of the half before it, the others right after its last MFMA -- a half's first MFMAs never wait for LDS.
+    // (the paired variant has two tile addresses to keep and no registers to spare: it reads every fragment after the MFMAs)
+    constexpr bool PF = !PAIR;
+    double2_t af[MT], bf[NT], pa_own, pb_own[NT];
+    double2_t &pa = PF ? pa_own : af[0];      // (without the prefetch the first half uses the plain set: one set of fragment registers)
+    double2_t *const pb = PF ? pb_own : bf;
+    {
+        const double *as = smem + aoff, *bs = smem + boff;
+        pa = *(const double2_t *)(as);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) pb[n] = *(const double2_t *)(bs + n * 16 * LSTR);
+#pragma unroll
+        for (int m = 1; m < MT; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR);
+    }
+#define GP_MMA(A_, B_, m_, n_, e_) acc[m_][n_] = __builtin_amdgcn_mfma_f64_16x16x4f64((A_)[e_], (B_)[e_], acc[m_][n_], 0, 0, MODE == 1 ? 1 : 0)
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         const bool more = (kt + 1 < nk);
@@ -237,23 +262,35 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? (BM < BT ? 2 : NWN) : 4)) v
         }
         const double *as = smem + buf * SBUF + aoff;
         const double *bs = smem + buf * SBUF + boff;
-        // Lane group lg owns k = 4lg..4lg+3 of the stage; MFMA step (h,e) contracts k = 4g + 2h + e
-        // over the four lane groups g, so two ds_read_b128 per operand row-tile feed four MFMA steps.
+        // ---- first half (k pairs 0, 1 of every lane group) ----
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double2_t af[MT], bf[NT];
+        for (int n = 0; n < NT; ++n) GP_MMA(pa, pb[n], 0, n, 0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR + h * 2);
+        for (int m = 1; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + h * 2);
+            for (int n = 0; n < NT; ++n) GP_MMA(af[m], pb[n], m, n, 0);
+        if (PF) {
+            __builtin_amdgcn_sched_barrier(0);
+            // (af[0] and bf[] are free here: the second half's leading fragments)
+            af[0] = *(const double2_t *)(as + 2);
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m][e], bf[n][e], acc[m][n], 0, 0, MODE == 1 ? 1 : 0);
+            for (int n = 0; n < NT; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + 2);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) GP_MMA(pa, pb[n], 0, n, 1);
+#pragma unroll
+        for (int m = 1; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) GP_MMA(af[m], pb[n], m, n, 1);
+        if (PF) __builtin_amdgcn_sched_barrier(0);
+        if (!PF) {
+            af[0] = *(const double2_t *)(as + 2);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + 2);
+        }
+#pragma unroll
+        for (int m = 1; m < MT; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR + 2);
         if (more) {
             double *As = smem + (buf ^ 1) * SBUF, *Bs = As + BM * LSTR;
 #pragma unroll
@@ -262,7 +299,37 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? (BM < BT ? 2 : NWN) : 4)) v
             for (int q = 0; q < LQ; ++q) *(double2_t *)(Bs + soff + q * LR * LSTR) = rb[q];
         }
         __syncthreads();
+        // ---- second half ----
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) GP_MMA(af[m], bf[n], m, n, 0);
+        const double *as2 = smem + (buf ^ 1) * SBUF + aoff, *bs2 = smem + (buf ^ 1) * SBUF + boff;
+        if (PF) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                pa = *(const double2_t *)(as2);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) pb[n] = *(const double2_t *)(bs2 + n * 16 * LSTR);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) GP_MMA(af[m], bf[n], m, n, 1);
+        if (PF) __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            if (!PF) {
+                pa = *(const double2_t *)(as2);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) pb[n] = *(const double2_t *)(bs2 + n * 16 * LSTR);
+            }
+#pragma unroll
+            for (int m = 1; m < MT; ++m) af[m] = *(const double2_t *)(as2 + m * 16 * LSTR);
+        }
     }
+#undef GP_MMA
 
 #pragma unroll
     for (int m = 0; m < MT; ++m)

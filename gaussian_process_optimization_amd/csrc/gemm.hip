@@ -233,22 +233,27 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? (BM < BT ? 2 : NWN) : 4)) v
     // overwrites it.  Lane group lg owns k = 4lg..4lg+3 of the stage; MFMA step (h,e) contracts k = 4g + 2h + e over the four lane
     // groups g, so two ds_read_b128 per operand row-tile feed four MFMA steps.
     // Fragment registers: the second half of a stage multiplies af[0..MT) x bf[0..NT); the first half multiplies
-    // {pa, af[1..MT)} x pb[0..NT): the three fragments the first MFMAs of a half need (row tile 0, every column tile) are read
-    // in the MIDDLE of the half before it, the others right after its last MFMA -- a half's first MFMAs never wait for LDS.
-    // (the paired variant has two tile addresses to keep and no registers to spare: it reads every fragment after the MFMAs)
-    constexpr bool PF = !PAIR;
-    double2_t af[MT], bf[NT], pa_own, pb_own[NT];
-    double2_t &pa = PF ? pa_own : af[0];      // (without the prefetch the first half uses the plain set: one set of fragment registers)
+    // {pa[0..PFA), af[PFA..MT)} x pb[0..NT).  The fragments the first MFMAs of a half need -- PFA row tiles and every column tile --
+    // are read in the MIDDLE of the half before it, the others right after its last MFMA: a half's first MFMAs never wait for
+    // LDS.  PFA = 1 where registers are short (the 8-wave variant: 113 -> 125 VGPRs, four waves per SIMD), every row tile where
+    // they are not (two waves per SIMD: a full second fragment set), none for the paired variant (two tile addresses to keep).
+    constexpr int PFA = PAIR ? 0 : ((BT == 128 && BM == 128 && NWN == 2) ? MT : 1);
+    constexpr bool PF = PFA > 0;
+    double2_t af[MT], bf[NT], pa_own[PF ? PFA : 1], pb_own[NT];
+    double2_t *const pa = PF ? pa_own : af;      // (without the prefetch the first half uses the plain set: one set of fragment registers)
     double2_t *const pb = PF ? pb_own : bf;
+    constexpr int PA = PF ? PFA : 1;             // leading A fragments of the first half live in pa[0..PA)
     {
         const double *as = smem + aoff, *bs = smem + boff;
-        pa = *(const double2_t *)(as);
+#pragma unroll
+        for (int m = 0; m < PA; ++m) pa[m] = *(const double2_t *)(as + m * 16 * LSTR);
 #pragma unroll
         for (int n = 0; n < NT; ++n) pb[n] = *(const double2_t *)(bs + n * 16 * LSTR);
 #pragma unroll
-        for (int m = 1; m < MT; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR);
+        for (int m = PA; m < MT; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR);
     }
 #define GP_MMA(A_, B_, m_, n_, e_) acc[m_][n_] = __builtin_amdgcn_mfma_f64_16x16x4f64((A_)[e_], (B_)[e_], acc[m_][n_], 0, 0, MODE == 1 ? 1 : 0)
+#define GP_A1(m_) ((m_) < PA ? pa[m_] : af[m_])
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         const bool more = (kt + 1 < nk);
@@ -264,25 +269,22 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? (BM < BT ? 2 : NWN) : 4)) v
         const double *bs = smem + buf * SBUF + boff;
         // ---- first half (k pairs 0, 1 of every lane group) ----
 #pragma unroll
-        for (int n = 0; n < NT; ++n) GP_MMA(pa, pb[n], 0, n, 0);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 1; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) GP_MMA(af[m], pb[n], m, n, 0);
+            for (int n = 0; n < NT; ++n) GP_MMA(GP_A1(m), pb[n], m, n, 0);
         if (PF) {
             __builtin_amdgcn_sched_barrier(0);
-            // (af[0] and bf[] are free here: the second half's leading fragments)
-            af[0] = *(const double2_t *)(as + 2);
+            // (af[0..PFA) and bf[] are free here: the second half's leading fragments)
+#pragma unroll
+            for (int m = 0; m < PFA; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR + 2);
 #pragma unroll
             for (int n = 0; n < NT; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + 2);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int n = 0; n < NT; ++n) GP_MMA(pa, pb[n], 0, n, 1);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 1; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) GP_MMA(af[m], pb[n], m, n, 1);
+            for (int n = 0; n < NT; ++n) GP_MMA(GP_A1(m), pb[n], m, n, 1);
         if (PF) __builtin_amdgcn_sched_barrier(0);
         if (!PF) {
             af[0] = *(const double2_t *)(as + 2);
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? (BM < BT ? 2 : NWN) : 4)) v
             for (int n = 0; n < NT; ++n) bf[n] = *(const double2_t *)(bs + n * 16 * LSTR + 2);
         }
 #pragma unroll
-        for (int m = 1; m < MT; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR + 2);
+        for (int m = PA; m < MT; ++m) af[m] = *(const double2_t *)(as + m * 16 * LSTR + 2);
         if (more) {
             double *As = smem + (buf ^ 1) * SBUF, *Bs = As + BM * LSTR;
 #pragma unroll
@@ -308,7 +310,8 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? (BM < BT ? 2 : NWN) : 4)) v
         if (PF) {
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
-                pa = *(const double2_t *)(as2);
+#pragma unroll
+                for (int m = 0; m < PFA; ++m) pa[m] = *(const double2_t *)(as2 + m * 16 * LSTR);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) pb[n] = *(const double2_t *)(bs2 + n * 16 * LSTR);
             }
@@ -321,14 +324,15 @@ __global__ __launch_bounds__(128 * NWN, (BT == 128 ? (BM < BT ? 2 : NWN) : 4)) v
         if (PF) __builtin_amdgcn_sched_barrier(0);
         if (more) {
             if (!PF) {
-                pa = *(const double2_t *)(as2);
+                pa[0] = *(const double2_t *)(as2);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) pb[n] = *(const double2_t *)(bs2 + n * 16 * LSTR);
             }
 #pragma unroll
-            for (int m = 1; m < MT; ++m) af[m] = *(const double2_t *)(as2 + m * 16 * LSTR);
+            for (int m = PA; m < MT; ++m) af[m] = *(const double2_t *)(as2 + m * 16 * LSTR);
         }
     }
+#undef GP_A1
 #undef GP_MMA
 
 #pragma unroll

@@ -99,6 +99,8 @@ int main() {
         long ntile = tileset_count(ts);
         for (int S : {0, 4, 8, 16}) {
             GemmOpt o;
+            if (getenv("GEMM_WAVES8")) o.waves8 = atoi(getenv("GEMM_WAVES8"));     // the 8-wave variant the library uses from 1024 tiles on
+            if (getenv("GEMM_STAGGER")) o.stagger = atoi(getenv("GEMM_STAGGER"));
             short *dl = nullptr;
             if (S) {
                 std::vector<short> l = build_tile_list(ts, S);

@@ -101,6 +101,7 @@ int main() {
             GemmOpt o;
             if (getenv("GEMM_WAVES8")) o.waves8 = atoi(getenv("GEMM_WAVES8"));     // the 8-wave variant the library uses from 1024 tiles on
             if (getenv("GEMM_STAGGER")) o.stagger = atoi(getenv("GEMM_STAGGER"));
+            if (getenv("GEMM_SMALL")) o.small = atoi(getenv("GEMM_SMALL"));        // 64 x 64 work units
             short *dl = nullptr;
             if (S) {
                 std::vector<short> l = build_tile_list(ts, S);

@@ -67,6 +67,8 @@ SIGNATURES = [
     ("gp_acq_lp_argbest", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                          ctypes.c_double, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, c_double_p,
                                          ctypes.c_int, c_int64_p, ctypes.c_int, c_int64_p, c_double_p]),
+    ("gp_acq_lp_grad", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
     ("gp_comm_unique_id", ctypes.c_int, [ctypes.c_char_p]),
     ("gp_comm_init", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     ("gp_comm_destroy", ctypes.c_int, [_vp]),
@@ -350,6 +352,15 @@ class Handle(object):
         check(self.lib, self.lib.gp_acq_lp(self.h, int(type_), float(par), float(fmin), float(y_mean), float(y_std),
                                            int(transform), pX, nb, pr, ps, dptr(out)), "gp_acq_lp")
         return out
+
+    def acq_lp_grad(self, type_, par, fmin, transform, Xb=None, r_x0=None, s_x0=None, y_mean=0.0, y_std=1.0):
+        """Penalised acquisition and its gradient at the resident candidates: (value[M], gradient[M, D])."""
+        keep, nb, pX, pr, ps = self._lp_args(Xb, r_x0, s_x0)
+        out = np.empty(self.M)
+        dout = np.empty((self.M, self.D))
+        check(self.lib, self.lib.gp_acq_lp_grad(self.h, int(type_), float(par), float(fmin), float(y_mean), float(y_std),
+                                                int(transform), pX, nb, pr, ps, dptr(out), dptr(dout)), "gp_acq_lp_grad")
+        return out, dout
 
     def acq_lp_argbest(self, type_, par, fmin, transform, sense, Xb=None, r_x0=None, s_x0=None, exclude=(),
                        y_mean=0.0, y_std=1.0):

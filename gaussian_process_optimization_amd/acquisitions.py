@@ -1,40 +1,49 @@
-"""Acquisition functions mirroring GPyOpt's (EI / LCB / MPI) with device-side batched scoring.
+"""EI / LCB / MPI and the local-penalisation batch acquisition, scored on the device.
 
-Reference: GPyOpt/GPyOpt/acquisitions/base.py:7-68 (AcquisitionBase: ``acquisition_function``
-returns the NEGATED value weighted by constraints and cost), EI.py:7-51, LCB.py:6-46,
-MPI.py:7-51, GPyOpt/GPyOpt/util/general.py:113-129 (get_quantiles).
+Contract mirrored (names, arguments, return shapes and signs): GPyOpt/GPyOpt/acquisitions/base.py:7-68
+(``acquisition_function`` returns the NEGATED value weighted by constraints and cost), EI.py:7-51, LCB.py:6-46, MPI.py:7-51,
+LP.py:10-140, GPyOpt/GPyOpt/core/evaluators/batch_local_penalization.py:7-70, GPyOpt/GPyOpt/util/general.py:113-129.
 
-``_compute_acq`` / ``_compute_acq_withGradients`` keep the reference's host formulas on top of
-``model.predict`` (so any BOModel works); when the model is the HIP ``GPModel`` and there are no
-constraints or cost, ``acquisition_function`` and ``argbest`` score the whole candidate table
-inside libgphip (gp_acq / gp_acq_argbest) -- the batched call pattern of
-GPyOpt/GPyOpt/optimization/anchor_points_generator.py:59,96-98 and run.py:1240-1241.
+Where the work runs.  With the HIP ``GPModel``, one output column, constant cost and no constraints, EVERY entry point goes to
+libgphip on the whole candidate block at once: values (``gp_acq``), values + x-gradients (``gp_acq_grad``), arg-best / top-k
+(``gp_acq_argbest`` / ``gp_acq_topk``), the penalised batch acquisition and its gradient (``gp_acq_lp`` / ``gp_acq_lp_grad``).
+Anything else (a foreign ``BOModel``, a cost model, string constraints, several outputs) is scored by ``_Rule`` below from
+``model.predict[_withGradients]``: each acquisition is one rule giving its value and its two partial derivatives with respect
+to the posterior mean and standard deviation, and every class shares the chain rule built on them.
 """
 import numpy as np
-from scipy.special import erfc
+from scipy.special import erfc, log_ndtr, ndtr
 
 from . import _lib
 from .gpmodel import GPModel
 
+_ROOT_2 = np.sqrt(2)
+_ROOT_2PI = np.sqrt(2 * np.pi)
+_STD_FLOOR = 1e-10
+
 
 def get_quantiles(acquisition_par, fmin, m, s):
-    """GPyOpt/GPyOpt/util/general.py:113-129."""
+    """Standardised improvement ``z = (fmin - m - par) / s`` with its normal density and distribution value, returned as
+    ``(pdf, cdf, z)``; ``s`` is floored at 1e-10 (in place for arrays).  Same contract as general.py:113-129."""
     if isinstance(s, np.ndarray):
-        s[s < 1e-10] = 1e-10
-    elif s < 1e-10:
-        s = 1e-10
-    u = (fmin - m - acquisition_par) / s
-    phi = np.exp(-0.5 * u ** 2) / np.sqrt(2 * np.pi)
-    Phi = 0.5 * erfc(-u / np.sqrt(2))
-    return (phi, Phi, u)
+        np.maximum(s, _STD_FLOOR, out=s)
+    else:
+        s = max(s, _STD_FLOOR)
+    z = (fmin - m - acquisition_par) / s
+    pdf = np.exp(-0.5 * z ** 2) / _ROOT_2PI
+    cdf = 0.5 * erfc(-z / _ROOT_2)
+    return pdf, cdf, z
 
 
 def constant_cost_withGradients(x):
-    """GPyOpt/GPyOpt/core/task/cost.py:76."""
-    return np.ones(x.shape[0])[:, None], np.zeros(x.shape)
+    """Unit cost and zero cost gradient (core/task/cost.py:76)."""
+    rows = x.shape[0]
+    return np.ones((rows, 1)), np.zeros(x.shape)
 
 
-class _NoConstraints(object):
+class _Unconstrained(object):
+    """Stand-in design space when none is given: every point feasible."""
+
     def indicator_constraints(self, x):
         return np.ones((np.atleast_2d(x).shape[0], 1))
 
@@ -42,114 +51,176 @@ class _NoConstraints(object):
         return False
 
 
+class _Rule(object):
+    """One acquisition as a function of the posterior mean ``mu`` and standard deviation ``sd`` (column vectors):
+    ``terms`` returns (value, d value / d mu, d value / d sd); the x-gradient follows by the chain rule in ``gradient``."""
+
+    def __init__(self, device_id, needs_fmin):
+        self.device_id = device_id
+        self.needs_fmin = needs_fmin
+
+    def terms(self, par, fmin, mu, sd):
+        raise NotImplementedError
+
+    def value(self, par, fmin, mu, sd):
+        return self.terms(par, fmin, mu, sd)[0]
+
+    def gradient(self, par, fmin, mu, sd, dmu_dx, dsd_dx):
+        val, wrt_mu, wrt_sd = self.terms(par, fmin, mu, sd)
+        return val, wrt_mu * dmu_dx + wrt_sd * dsd_dx
+
+
+class _ExpectedImprovement(_Rule):
+    def terms(self, par, fmin, mu, sd):
+        pdf, cdf, z = get_quantiles(par, fmin, mu, sd)
+        return sd * (z * cdf + pdf), -cdf, pdf
+
+
+class _LowerConfidenceBound(_Rule):
+    def terms(self, par, fmin, mu, sd):
+        return -mu + par * sd, -1.0, par
+
+
+class _ProbabilityOfImprovement(_Rule):
+    def terms(self, par, fmin, mu, sd):
+        pdf, cdf, z = get_quantiles(par, fmin, mu, sd)
+        slope = -(pdf / sd)
+        return cdf, slope, slope * z
+
+
+_RULES = {"EI": _ExpectedImprovement(_lib.GP_ACQ_EI, True),
+          "LCB": _LowerConfidenceBound(_lib.GP_ACQ_LCB, False),
+          "MPI": _ProbabilityOfImprovement(_lib.GP_ACQ_MPI, True)}
+
+
+def _pick(values, sense):
+    """Lowest-index arg-best of a 1-D score vector (NumPy argmin / argmax semantics)."""
+    i = int(np.argmin(values) if sense < 0 else np.argmax(values))
+    return i, float(values[i])
+
+
 class AcquisitionBase(object):
-    """acquisitions/base.py:7-68."""
+    """base.py:7-68.  Subclasses either name a ``_rule`` (EI / LCB / MPI) or override ``_compute_acq`` /
+    ``_compute_acq_withGradients`` as in GPyOpt."""
     analytical_gradient_prediction = False
-    _acq_id = None
+    _rule = None
 
     def __init__(self, model, space=None, optimizer=None, cost_withGradients=None):
         self.model = model
-        self.space = space if space is not None else _NoConstraints()
+        self.space = _Unconstrained() if space is None else space
         self.optimizer = optimizer
         self.analytical_gradient_acq = self.analytical_gradient_prediction and self.model.analytical_gradient_prediction
-        self.cost_withGradients = constant_cost_withGradients if cost_withGradients is None else cost_withGradients
+        self.cost_withGradients = cost_withGradients or constant_cost_withGradients
 
-    # -- device fast path ---------------------------------------------------------------
-    def _device_ok(self):
-        if not isinstance(self.model, GPModel) or self._acq_id is None or self.model.model is None:
-            return False
-        if self.cost_withGradients is not constant_cost_withGradients:
-            return False
-        has = getattr(self.space, "has_constraints", None)
-        if has is not None and has():
-            return False
-        return self.model.model.output_dim == 1
+    # ---- what the rule needs ---------------------------------------------------------------------------------------
+    @property
+    def _acq_id(self):
+        return None if self._rule is None else self._rule.device_id
 
     def _par(self):
         raise NotImplementedError
 
+    def _fmin(self):
+        return self.model.get_fmin() if self._rule.needs_fmin else 0.0
+
+    # ---- device route ----------------------------------------------------------------------------------------------
+    def _device_ok(self):
+        """True when libgphip can score this acquisition by itself: our GPModel, one output, unit cost, no constraints."""
+        if self._rule is None or not isinstance(self.model, GPModel) or self.model.model is None:
+            return False
+        if self.cost_withGradients is not constant_cost_withGradients:
+            return False
+        constrained = getattr(self.space, "has_constraints", None)
+        if constrained is not None and constrained():
+            return False
+        return self.model.model.output_dim == 1
+
     def _device_stage(self, x):
+        """Make ``x`` the resident candidate block (refitting first if data or hyper-parameters changed) and return what
+        every device scoring call takes: the handle owner, fmin and the normaliser's mean / std."""
         gp = self.model.model
         x = np.atleast_2d(np.asarray(x, dtype=float))
         if gp._dirty:
-            # a refit is pending (new data / hyper-parameters): fit and the posterior at x go down as one call
-            gp._stage(x, fit=False)
-            gp._predict_resident(True)   # GPModel.predict: with_noise=True (gpmodel.py:102); kept resident on the device
+            gp._stage(x, fit=False)        # pending refit: fit + posterior at x go down as ONE call
+            gp._predict_resident(True)     # GPModel.predict: with_noise=True (gpmodel.py:102)
         else:
             gp._stage(x)
         nz = gp.normalizer
-        y_mean = float(nz.mean[0]) if nz is not None else 0.0
-        y_std = float(nz.std[0]) if nz is not None else 1.0
-        fmin = self.model.get_fmin() if self._acq_id != _lib.GP_ACQ_LCB else 0.0
-        return gp, fmin, y_mean, y_std
+        shift, scale = (0.0, 1.0) if nz is None else (float(nz.mean[0]), float(nz.std[0]))
+        return gp, self._fmin(), shift, scale
 
+    # ---- the contract ----------------------------------------------------------------------------------------------
     def acquisition_function(self, x):
-        """base.py:33-39: -(acq * indicator_constraints) / cost."""
+        """-(acq(x) * feasibility(x)) / cost(x), [M, 1]  (base.py:33-39)."""
         if self._device_ok():
-            gp, fmin, y_mean, y_std = self._device_stage(x)
-            return gp._h.acq(self._acq_id, self._par(), fmin, y_mean, y_std)
-        f_acqu = self._compute_acq(x)
-        cost_x, _ = self.cost_withGradients(x)
-        return -(f_acqu * self.space.indicator_constraints(x)) / cost_x
+            gp, fmin, shift, scale = self._device_stage(x)
+            return gp._h.acq(self._acq_id, self._par(), fmin, shift, scale)
+        price, _ = self.cost_withGradients(x)
+        return -(self._compute_acq(x) * self.space.indicator_constraints(x)) / price
 
     def acquisition_function_withGradients(self, x):
-        """base.py:42-50."""
-        f_acqu, df_acqu = self._compute_acq_withGradients(x)
-        cost_x, cost_grad_x = self.cost_withGradients(x)
-        f_acq_cost = f_acqu / cost_x
-        df_acq_cost = (df_acqu * cost_x - f_acqu * cost_grad_x) / (cost_x ** 2)
-        ind = self.space.indicator_constraints(x)
-        return -f_acq_cost * ind, -df_acq_cost * ind
+        """The same value and its x-gradient [M, D]  (base.py:42-50)."""
+        if self._device_ok():
+            gp, fmin, shift, scale = self._device_stage(x)
+            return gp._h.acq_grad(self._acq_id, self._par(), fmin, shift, scale)
+        val, dval = self._compute_acq_withGradients(x)
+        price, dprice = self.cost_withGradients(x)
+        feasible = self.space.indicator_constraints(x)
+        quotient = val / price
+        dquotient = (dval * price - val * dprice) / (price ** 2)
+        return -quotient * feasible, -dquotient * feasible
 
     def argbest(self, x, sense=-1):
-        """Index and value of the best row of ``acquisition_function(x)``.
-
-        sense=-1: the smallest (GPyOpt's convention, anchor_points_generator.py:61);
-        sense=+1: the largest (run.py:1241 takes ``np.argmax``).  Ties -> lowest index.
-        """
+        """Row index and value of the best entry of ``acquisition_function(x)``: sense=-1 the smallest (GPyOpt's convention,
+        anchor_points_generator.py:61), sense=+1 the largest (run.py:1241 takes ``np.argmax``).  Ties -> lowest index."""
         if self._device_ok():
-            gp, fmin, y_mean, y_std = self._device_stage(x)
-            return gp._h.acq_argbest(self._acq_id, self._par(), fmin, sense, y_mean, y_std)
-        a = self.acquisition_function(x)[:, 0]
-        i = int(np.argmin(a) if sense < 0 else np.argmax(a))
-        return i, float(a[i])
+            gp, fmin, shift, scale = self._device_stage(x)
+            return gp._h.acq_argbest(self._acq_id, self._par(), fmin, sense, shift, scale)
+        return _pick(self.acquisition_function(x)[:, 0], sense)
 
     def topk(self, x, k, sense=-1):
-        """The ``k`` best rows of ``acquisition_function(x)`` in order, (indices, values): what
-        ``AnchorPointsGenerator.get`` keeps (anchor_points_generator.py:59-61, ``argsort(scores)[:num_anchor]``).
-        Equal scores come out lowest index first; fewer than ``k`` rows -> the tail is index -1."""
+        """The ``k`` best rows in order, (indices, values): what ``AnchorPointsGenerator.get`` keeps
+        (anchor_points_generator.py:59-61).  Equal scores lowest index first; fewer than ``k`` rows -> index -1 in the tail."""
         if self._device_ok() and k <= 64:
-            gp, fmin, y_mean, y_std = self._device_stage(x)
-            return gp._h.acq_topk(self._acq_id, self._par(), fmin, sense, k, y_mean, y_std)
-        a = self.acquisition_function(x)[:, 0]
-        order = np.argsort(a if sense < 0 else -a, kind="stable")[:k]
+            gp, fmin, shift, scale = self._device_stage(x)
+            return gp._h.acq_topk(self._acq_id, self._par(), fmin, sense, k, shift, scale)
+        scores = self.acquisition_function(x)[:, 0]
+        ranked = np.argsort(scores if sense < 0 else -scores, kind="stable")[:k]
         idx = np.full(k, -1, dtype=np.int64)
         val = np.full(k, np.inf if sense < 0 else -np.inf)
-        idx[:order.size], val[:order.size] = order, a[order]
+        idx[:ranked.size] = ranked
+        val[:ranked.size] = scores[ranked]
         return idx, val
 
     def optimize(self, duplicate_manager=None):
-        """base.py:52-60."""
-        if not self.analytical_gradient_acq:
-            return self.optimizer.optimize(f=self.acquisition_function, duplicate_manager=duplicate_manager)
-        return self.optimizer.optimize(f=self.acquisition_function, f_df=self.acquisition_function_withGradients,
-                                       duplicate_manager=duplicate_manager)
+        """Hand the (negated) acquisition to the acquisition optimiser (base.py:52-60)."""
+        kw = dict(f=self.acquisition_function, duplicate_manager=duplicate_manager)
+        if self.analytical_gradient_acq:
+            kw["f_df"] = self.acquisition_function_withGradients
+        return self.optimizer.optimize(**kw)
 
+    # ---- host scoring from model.predict (foreign models, cost, constraints) -----------------------------------------
     def _compute_acq(self, x):
-        raise NotImplementedError('')
+        if self._rule is None:
+            raise NotImplementedError('a subclass without a _rule scores itself')
+        mu, sd = self.model.predict(x)
+        return self._rule.value(self._par(), self._fmin(), mu, sd)
 
     def _compute_acq_withGradients(self, x):
-        raise NotImplementedError('')
+        if self._rule is None:
+            raise NotImplementedError('a subclass without a _rule scores itself')
+        fmin = self._fmin()
+        mu, sd, dmu_dx, dsd_dx = self.model.predict_withGradients(x)
+        return self._rule.gradient(self._par(), fmin, mu, sd, dmu_dx, dsd_dx)
 
 
 class AcquisitionEI(AcquisitionBase):
-    """Expected improvement, EI.py:7-51."""
+    """Expected improvement (EI.py:7-51): ``jitter`` is the improvement margin."""
     analytical_gradient_prediction = True
-    _acq_id = _lib.GP_ACQ_EI
+    _rule = _RULES["EI"]
 
     def __init__(self, model, space=None, optimizer=None, cost_withGradients=None, jitter=0.01):
-        self.optimizer = optimizer
-        super(AcquisitionEI, self).__init__(model, space, optimizer, cost_withGradients=cost_withGradients)
+        super().__init__(model, space, optimizer, cost_withGradients=cost_withGradients)
         self.jitter = jitter
 
     @staticmethod
@@ -159,29 +230,14 @@ class AcquisitionEI(AcquisitionBase):
     def _par(self):
         return self.jitter
 
-    def _compute_acq(self, x):
-        m, s = self.model.predict(x)
-        fmin = self.model.get_fmin()
-        phi, Phi, u = get_quantiles(self.jitter, fmin, m, s)
-        return s * (u * Phi + phi)
-
-    def _compute_acq_withGradients(self, x):
-        fmin = self.model.get_fmin()
-        m, s, dmdx, dsdx = self.model.predict_withGradients(x)
-        phi, Phi, u = get_quantiles(self.jitter, fmin, m, s)
-        f_acqu = s * (u * Phi + phi)
-        df_acqu = dsdx * phi - Phi * dmdx
-        return f_acqu, df_acqu
-
 
 class AcquisitionLCB(AcquisitionBase):
-    """GP lower confidence bound, LCB.py:6-46."""
+    """GP lower confidence bound (LCB.py:6-46); a cost model is ignored, as in the reference."""
     analytical_gradient_prediction = True
-    _acq_id = _lib.GP_ACQ_LCB
+    _rule = _RULES["LCB"]
 
     def __init__(self, model, space=None, optimizer=None, cost_withGradients=None, exploration_weight=2):
-        self.optimizer = optimizer
-        super(AcquisitionLCB, self).__init__(model, space, optimizer)
+        super().__init__(model, space, optimizer)
         self.exploration_weight = exploration_weight
         if cost_withGradients is not None:
             print('The set cost function is ignored! LCB acquisition does not make sense with cost.')
@@ -193,23 +249,14 @@ class AcquisitionLCB(AcquisitionBase):
     def _par(self):
         return self.exploration_weight
 
-    def _compute_acq(self, x):
-        m, s = self.model.predict(x)
-        return -m + self.exploration_weight * s
-
-    def _compute_acq_withGradients(self, x):
-        m, s, dmdx, dsdx = self.model.predict_withGradients(x)
-        return -m + self.exploration_weight * s, -dmdx + self.exploration_weight * dsdx
-
 
 class AcquisitionMPI(AcquisitionBase):
-    """Maximum probability of improvement, MPI.py:7-51."""
+    """Maximum probability of improvement (MPI.py:7-51)."""
     analytical_gradient_prediction = True
-    _acq_id = _lib.GP_ACQ_MPI
+    _rule = _RULES["MPI"]
 
     def __init__(self, model, space=None, optimizer=None, cost_withGradients=None, jitter=0.01):
-        self.optimizer = optimizer
-        super(AcquisitionMPI, self).__init__(model, space, optimizer, cost_withGradients=cost_withGradients)
+        super().__init__(model, space, optimizer, cost_withGradients=cost_withGradients)
         self.jitter = jitter
 
     @staticmethod
@@ -219,210 +266,178 @@ class AcquisitionMPI(AcquisitionBase):
     def _par(self):
         return self.jitter
 
-    def _compute_acq(self, x):
-        m, s = self.model.predict(x)
-        fmin = self.model.get_fmin()
-        _, Phi, _ = get_quantiles(self.jitter, fmin, m, s)
-        return Phi
 
-    def _compute_acq_withGradients(self, x):
-        fmin = self.model.get_fmin()
-        m, s, dmdx, dsdx = self.model.predict_withGradients(x)
-        phi, Phi, u = get_quantiles(self.jitter, fmin, m, s)
-        return Phi, -(phi / s) * (dmdx + dsdx * u)
+# ---- local penalisation ---------------------------------------------------------------------------------------------
+def _log_transform(acq, transform):
+    """(log T(acq), d log T / d acq) of the positive base acquisition: T = identity ('none': log(acq + 1e-50), slope
+    1 / acq) or softplus (log of log(1 + e^acq), taken as log(acq) from 40 on; slope 1 / (softplus (1 + e^-acq)))."""
+    acq = np.asarray(acq, dtype=float)
+    if transform == 'softplus':
+        big = acq >= 40.
+        soft = np.log1p(np.exp(acq))
+        return np.where(big, np.log(np.where(big, acq, 1.0)), np.log(soft)), 1. / (soft * (1. + np.exp(-acq)))
+    if transform == 'none':
+        return np.log(acq + 1e-50), 1. / acq
+    return acq, np.ones_like(acq)
+
+
+def _exclusion(x, centres, radius, width):
+    """Per (point, centre): z = (|x - centre| - radius) / width and the distance itself, [M, nb] each."""
+    gap = np.atleast_2d(x)[:, None, :] - np.atleast_2d(centres)[None, :, :]
+    dist = np.sqrt(np.square(gap).sum(-1))
+    return (dist - radius) / width, dist
 
 
 class AcquisitionLP(AcquisitionBase):
-    """Local-penalisation acquisition for batch design, GPyOpt/GPyOpt/acquisitions/LP.py:10-140.
-
-    Always in log space: ``-T(acq(x)) - sum_k log Phi((|x - x0_k| - r_k) / s_k)``.  On the HIP path the whole
-    candidate table is scored on the device (gp_acq_lp: the base EI / LCB / MPI kernel plus the hammer-function
-    epilogue); the reference's NumPy formulas remain as the path for foreign models and for gradients.
-    """
+    """Local-penalisation wrapper of a base acquisition for batch design (Gonzalez et al. 2016; LP.py:10-140), always in log
+    space: ``-log T(acq(x)) - sum_k log Phi((|x - x_k| - r_k) / s_k)`` over the batch points x_k chosen so far."""
     analytical_gradient_prediction = True
 
     def __init__(self, model, space=None, optimizer=None, acquisition=None, transform='none'):
-        super(AcquisitionLP, self).__init__(model, space, optimizer)
+        super().__init__(model, space, optimizer)
         self.acq = acquisition
-        self.transform = transform.lower()
-        if isinstance(acquisition, AcquisitionLCB) and self.transform == 'none':
-            self.transform = 'softplus'                      # LP.py:32-35
-        self.X_batch = None
-        self.r_x0 = None
-        self.s_x0 = None
+        kind = str(transform).lower()
+        # LCB can be negative, so its plain logarithm is replaced by log(softplus) (LP.py:32-35)
+        self.transform = 'softplus' if (kind == 'none' and isinstance(acquisition, AcquisitionLCB)) else kind
+        self.X_batch = self.r_x0 = self.s_x0 = None
 
     def update_batches(self, X_batch, L, Min):
-        """LP.py:41-47."""
-        self.X_batch = X_batch
-        if X_batch is not None:
-            self.r_x0, self.s_x0 = self._hammer_function_precompute(X_batch, L, Min, self.model)
+        """Set (or with None: clear) the batch chosen so far; radii and widths of its exclusion balls come from the model's
+        prediction at the batch, the Lipschitz constant ``L`` and the best observed value ``Min`` (LP.py:41-62)."""
+        self.X_batch, have_batch = X_batch, X_batch is not None
+        if have_batch:
+            self.r_x0, self.s_x0 = self._ball_parameters(X_batch, L, Min)
 
-    def _hammer_function_precompute(self, x0, L, Min, model):
-        """LP.py:49-62 (the reference feeds the model's *std* into ``pred`` and takes its square root again)."""
-        if x0 is None:
-            return None, None
-        if len(x0.shape) == 1:
-            x0 = x0[None, :]
-        m = model.predict(x0)[0]
-        pred = model.predict(x0)[1].copy()
-        pred[pred < 1e-16] = 1e-16
-        s = np.sqrt(pred)
-        r_x0 = (m - Min) / L
-        s_x0 = s / L
-        return r_x0.flatten(), s_x0.flatten()
+    def _ball_parameters(self, centres, L, Min):
+        mu, spread = self.model.predict(np.atleast_2d(centres))
+        # the reference floors what ``predict`` returns as its second output (a standard deviation here) at 1e-16 and takes
+        # the square root of it once more; kept, since r / s define the batch the reference would pick
+        width = np.sqrt(np.maximum(spread, 1e-16)) / L
+        return ((mu - Min) / L).ravel(), width.ravel()
 
-    def _hammer_function(self, x, x0, r_x0, s_x0):
-        """LP.py:64-68."""
-        from scipy.stats import norm
-        return norm.logcdf((np.sqrt((np.square(np.atleast_2d(x)[:, None, :] - np.atleast_2d(x0)[None, :, :])).sum(-1))
-                            - r_x0) / s_x0)
+    # -- host scoring (foreign models) -------------------------------------------------------------------------------
+    def _score_on_host(self, x):
+        with np.errstate(over='ignore'):
+            logt, _ = _log_transform(-self.acq.acquisition_function(x)[:, 0], self.transform)
+        score = -logt
+        if self.X_batch is not None:
+            z, _ = _exclusion(x, self.X_batch, self.r_x0, self.s_x0)
+            score = score - log_ndtr(z).sum(axis=-1)
+        return score
 
-    def _penalized_acquisition(self, x, model, X_batch, r_x0, s_x0):
-        """LP.py:70-89 (host formulas)."""
-        fval = -self.acq.acquisition_function(x)[:, 0]
-        if self.transform == 'softplus':
-            fval_org = fval.copy()
-            fval[fval_org >= 40.] = np.log(fval_org[fval_org >= 40.])
-            fval[fval_org < 40.] = np.log(np.log1p(np.exp(fval_org[fval_org < 40.])))
-        elif self.transform == 'none':
-            fval = np.log(fval + 1e-50)
-        fval = -fval
-        if X_batch is not None:
-            h_vals = self._hammer_function(x, X_batch, r_x0, s_x0)
-            fval += -h_vals.sum(axis=-1)
-        return fval
+    def _penalty_slope(self, x):
+        """What the reference subtracts from every gradient component (LP.py:91-103): sum over the batch of
+        pdf(z) / (s Phi(z) |x - x_k|) -- the direction factor is absent there, and so here."""
+        z, dist = _exclusion(x, self.X_batch, self.r_x0, self.s_x0)
+        mass = ndtr(z)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            term = 1. / (self.s_x0 * _ROOT_2PI * mass) * np.exp(-np.square(z) / 2) / dist
+        term[mass < 1e-50] = 0.
+        return term.sum(axis=1)[:, None]
 
-    def _d_hammer_function(self, x, X_batch, r_x0, s_x0):
-        """LP.py:91-103."""
-        from scipy.stats import norm
-        dx = np.atleast_2d(x)[:, None, :] - np.atleast_2d(X_batch)[None, :, :]
-        nm = np.sqrt((np.square(dx)).sum(-1))
-        z = (nm - r_x0) / s_x0
-        h_func = norm.cdf(z)
-        d = 1. / (s_x0 * np.sqrt(2 * np.pi) * h_func) * np.exp(-np.square(z) / 2) / nm
-        d[h_func < 1e-50] = 0.
-        d = d[:, :, None]
-        return d.sum(axis=1)
-
-    # -- device fast path -----------------------------------------------------------------
+    # -- device route ------------------------------------------------------------------------------------------------
     def _lp_device_ok(self):
-        return (self.acq is not None and self.acq.model is self.model and self.acq._device_ok()
-                and self.transform in ('none', 'softplus'))
+        base = self.acq
+        return base is not None and base.model is self.model and base._device_ok() and self.transform in ('none', 'softplus')
 
-    def _lp_device_args(self, x):
-        gp, fmin, y_mean, y_std = self.acq._device_stage(x)
-        tr = 1 if self.transform == 'softplus' else 0
-        return gp, (self.acq._acq_id, self.acq._par(), fmin, tr), dict(Xb=self.X_batch, r_x0=self.r_x0, s_x0=self.s_x0,
-                                                                      y_mean=y_mean, y_std=y_std)
+    def _lp_call(self, x):
+        base = self.acq
+        gp, fmin, shift, scale = base._device_stage(x)
+        head = (base._acq_id, base._par(), fmin, 1 if self.transform == 'softplus' else 0)
+        batch = dict(Xb=self.X_batch, r_x0=self.r_x0, s_x0=self.s_x0, y_mean=shift, y_std=scale)
+        return gp._h, head, batch
 
     def acquisition_function(self, x):
-        """LP.py:105-110.  Returns a 1-D array like the reference."""
+        """1-D array like the reference's (LP.py:105-110)."""
         if self._lp_device_ok():
-            gp, a, kw = self._lp_device_args(x)
-            return gp._h.acq_lp(*a, **kw)
-        return self._penalized_acquisition(x, self.model, self.X_batch, self.r_x0, self.s_x0)
-
-    def argbest(self, x, sense=+1, exclude=()):
-        """Arg-best of ``acquisition_function(x)`` with already-chosen rows masked (run.py:1241,1249-1252)."""
-        if self._lp_device_ok():
-            gp, a, kw = self._lp_device_args(x)
-            return gp._h.acq_lp_argbest(a[0], a[1], a[2], a[3], sense, exclude=exclude, **kw)
-        v = np.ma.array(self.acquisition_function(x), mask=False)
-        for e in exclude:
-            v.mask[e] = True
-        i = int(np.argmax(v) if sense > 0 else np.argmin(v))
-        return i, float(v[i])
+            h, head, batch = self._lp_call(x)
+            return h.acq_lp(*head, **batch)
+        return self._score_on_host(x)
 
     def d_acquisition_function(self, x):
-        """LP.py:112-133."""
-        x = np.atleast_2d(x)
-        if self.transform == 'softplus':
-            fval = -self.acq.acquisition_function(x)[:, 0]
-            scale = 1. / (np.log1p(np.exp(fval)) * (1. + np.exp(-fval)))
-        elif self.transform == 'none':
-            fval = -self.acq.acquisition_function(x)[:, 0]
-            scale = 1. / fval
-        else:
-            scale = 1.
-        # the reference multiplies a length-M vector with an [M, D] gradient, which only broadcasts for the
-        # single-row calls L-BFGS makes; a column keeps those values and also serves M > 1
-        scale = np.atleast_1d(scale)[:, None] if np.ndim(scale) else scale
-        _, grad_acq_x = self.acq.acquisition_function_withGradients(x)
-        if self.X_batch is None:
-            return scale * grad_acq_x
-        return scale * grad_acq_x - self._d_hammer_function(x, self.X_batch, self.r_x0, self.s_x0)
+        return self.acquisition_function_withGradients(x)[1]
 
     def acquisition_function_withGradients(self, x):
-        """LP.py:135-140."""
-        return self.acquisition_function(x), self.d_acquisition_function(x)
+        """(value [M], gradient [M, D])  (LP.py:112-140)."""
+        x = np.atleast_2d(np.asarray(x, dtype=float))
+        if self._lp_device_ok():
+            h, head, batch = self._lp_call(x)
+            return h.acq_lp_grad(*head, **batch)
+        neg, dneg = self.acq.acquisition_function_withGradients(x)
+        with np.errstate(over='ignore', divide='ignore'):
+            _, slope = _log_transform(-neg[:, 0], self.transform)
+        grad = slope[:, None] * dneg
+        if self.X_batch is not None:
+            grad = grad - self._penalty_slope(x)
+        return self.acquisition_function(x), grad
+
+    def argbest(self, x, sense=+1, exclude=()):
+        """Arg-best of ``acquisition_function(x)`` with the rows in ``exclude`` masked out (run.py:1241,1249-1252)."""
+        if self._lp_device_ok():
+            h, head, batch = self._lp_call(x)
+            return h.acq_lp_argbest(head[0], head[1], head[2], head[3], sense, exclude=exclude, **batch)
+        scores = np.array(self.acquisition_function(x), dtype=float)
+        scores[list(exclude)] = -np.inf if sense > 0 else np.inf
+        return _pick(scores, sense)
 
 
 def estimate_L(model, bounds, storehistory=True):
-    """Lipschitz constant of the posterior mean, GPyOpt/GPyOpt/core/evaluators/batch_local_penalization.py:52-70.
+    """Lipschitz constant of the posterior mean over the box ``bounds``: the largest |d mean / dx| over 500 uniform draws
+    plus the training inputs, polished by L-BFGS-B from the best of them; 10 for a flat model
+    (core/evaluators/batch_local_penalization.py:52-70).  ``model`` is the GP (``GPModel.model``): all 500 + N predictive
+    gradients come from ONE batched device call."""
+    from scipy.optimize import minimize
 
-    ``model`` is the GP (``GPModel.model``); its predictive gradients over the 500 + N sample points come from
-    one batched device call."""
-    from scipy import optimize as _sopt
+    def neg_slope(pts):
+        jac, _ = model.predictive_gradients(np.atleast_2d(pts))
+        return -np.sqrt((jac * jac).sum(1))
 
-    def df(x, model, x0):
-        x = np.atleast_2d(x)
-        dmdx, _ = model.predictive_gradients(x)
-        res = np.sqrt((dmdx * dmdx).sum(1))
-        return -res
-
-    bounds = list(bounds)
-    lo = np.array([b[0] for b in bounds], dtype=float)
-    hi = np.array([b[1] for b in bounds], dtype=float)
-    samples = np.random.uniform(size=(500, len(bounds))) * (hi - lo) + lo     # samples_multidimensional_uniform
-    samples = np.vstack([samples, model.X])
-    pred_samples = df(samples, model, 0)
-    x0 = samples[np.argmin(pred_samples)]
-    res = _sopt.minimize(lambda x: float(df(x, model, x0).ravel()[0]), x0, method='L-BFGS-B', bounds=bounds,
-                         options={'maxiter': 200})
-    L = -float(res.fun)
-    if L < 1e-7:
-        L = 10  # flat model
-    return L
+    box = np.asarray(list(bounds), dtype=float)
+    draws = np.random.uniform(size=(500, box.shape[0])) * (box[:, 1] - box[:, 0]) + box[:, 0]
+    pool = np.vstack([draws, model.X])
+    start = pool[np.argmin(neg_slope(pool))]
+    polished = minimize(lambda p: float(neg_slope(p).ravel()[0]), start, method='L-BFGS-B', bounds=[tuple(b) for b in box],
+                        options={'maxiter': 200})
+    steepest = -float(polished.fun)
+    return steepest if steepest >= 1e-7 else 10
 
 
 class LocalPenalization(object):
-    """Batch evaluator of Gonzalez et al. 2016, core/evaluators/batch_local_penalization.py:7-49."""
+    """Batch evaluator: pick ``batch_size`` points one after the other, each time penalising the acquisition around the
+    points already chosen (core/evaluators/batch_local_penalization.py:7-49)."""
 
     def __init__(self, acquisition, batch_size):
         self.acquisition = acquisition
         self.batch_size = batch_size
 
+    def _constants(self):
+        gp = self.acquisition.model.model
+        return estimate_L(gp, self.acquisition.space.get_bounds()), gp.Y.min()
+
     def compute_batch(self, duplicate_manager=None, context_manager=None):
-        assert isinstance(self.acquisition, AcquisitionLP)
-        self.acquisition.update_batches(None, None, None)
-        X_batch = self.acquisition.optimize()[0]
-        k = 1
-        if self.batch_size > 1:
-            L = estimate_L(self.acquisition.model.model, self.acquisition.space.get_bounds())
-            Min = self.acquisition.model.model.Y.min()
-        while k < self.batch_size:
-            self.acquisition.update_batches(X_batch, L, Min)
-            new_sample = self.acquisition.optimize()[0]
-            X_batch = np.vstack((X_batch, new_sample))
-            k += 1
-        self.acquisition.update_batches(None, None, None)
-        return X_batch
+        """Batch by optimising the (penalised) acquisition over the domain."""
+        lp = self.acquisition
+        assert isinstance(lp, AcquisitionLP)
+        lp.update_batches(None, None, None)
+        batch = lp.optimize()[0]
+        if self.batch_size >= 2:
+            lipschitz, best_seen = self._constants()
+            for _ in range(self.batch_size - 1):
+                lp.update_batches(batch, lipschitz, best_seen)
+                batch = np.vstack((batch, lp.optimize()[0]))
+        lp.update_batches(None, None, None)
+        return batch
 
     def compute_batch_from_table(self, table, sense=+1):
-        """The candidate-table variant the thesis driver uses (run.py:1234-1258): pick ``batch_size`` rows of
-        ``table`` by repeated arg-best of the penalised acquisition, never the same row twice."""
-        acq = self.acquisition
-        acq.update_batches(None, None, None)
-        i, _ = acq.argbest(table, sense)
-        chosen = [i]
-        X_batch = table[i]
-        if self.batch_size > 1:
-            L = estimate_L(acq.model.model, acq.space.get_bounds())
-            Min = acq.model.model.Y.min()
-        while len(chosen) < self.batch_size:
-            acq.update_batches(np.atleast_2d(X_batch), L, Min)
-            i, _ = acq.argbest(table, sense, exclude=chosen)
-            chosen.append(i)
-            X_batch = np.vstack((X_batch, table[i]))
-        acq.update_batches(None, None, None)
-        return chosen
+        """The candidate-table variant the thesis driver uses (run.py:1234-1258): ``batch_size`` distinct rows of ``table`` by
+        repeated arg-best of the penalised acquisition."""
+        lp = self.acquisition
+        lp.update_batches(None, None, None)
+        rows = [lp.argbest(table, sense)[0]]
+        if self.batch_size >= 2:
+            lipschitz, best_seen = self._constants()
+            while len(rows) < self.batch_size:
+                lp.update_batches(np.atleast_2d(table[rows]), lipschitz, best_seen)
+                rows.append(lp.argbest(table, sense, exclude=rows)[0])
+        lp.update_batches(None, None, None)
+        return rows

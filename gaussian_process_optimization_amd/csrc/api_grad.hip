@@ -127,20 +127,48 @@ extern "C" int gp_predict_grad(gp_t *g, double *dmdx, double *dvdx) {
     return 0;
 }
 
+static int run_acq_grad(gp_ctx *g, int type, double par, double fmin, double y_mean, double y_std);
+
 extern "C" int gp_acq_grad(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, double *out, double *dout) {
     if (!g || !out || !dout) return fail(GP_ERR_ARG, "null argument");
     GP_DEAD_CHECK(g);
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = run_acq_grad(g, type, par, fmin, y_mean, y_std))) return rc;
+    HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipMemcpyAsync(dout, g->dDacq, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));
+    HIPCHK(hipStreamSynchronize(g->s));
+    return 0;
+}
+
+// the base acquisition's negated value and gradient of every resident candidate into dAcq [M] and dDacq [M, D]
+static int run_acq_grad(gp_ctx *g, int type, double par, double fmin, double y_mean, double y_std) {
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     if (g->P != 1) return fail(GP_ERR_ARG, "acquisitions need P == 1");
     if (type < GP_ACQ_EI || type > GP_ACQ_MPI) return fail(GP_ERR_ARG, "unknown acquisition %d", type);
-    HIPCHK(hipSetDevice(g->device));
     int rc;
     if ((rc = ensure_out(g))) return rc;
     if ((rc = run_predict_grad(g))) return rc;
     if ((rc = run_predict(g, 1))) return rc;
     launch_acq_grad(g->s, type, par, fmin, y_mean, y_std, g->dMean, g->dVar, g->dDm, g->dDv, g->M, g->D, g->dAcq,
                     g->dDacq);
+    return 0;
+}
+
+// AcquisitionLP.acquisition_function_withGradients (GPyOpt/GPyOpt/acquisitions/LP.py:112-140): the base acquisition's value
+// and gradient, then the log transform and the penaliser as an epilogue over the same buffers.
+extern "C" int gp_acq_lp_grad(gp_t *g, int type, double par, double fmin, double y_mean, double y_std, int transform,
+                              const double *Xb, int nb, const double *r_x0, const double *s_x0, double *out, double *dout) {
+    if (!g || !out || !dout || (nb > 0 && (!Xb || !r_x0 || !s_x0))) return fail(GP_ERR_ARG, "null argument");
+    GP_DEAD_CHECK(g);
+    if (transform != 0 && transform != 1) return fail(GP_ERR_ARG, "transform must be 0 (none) or 1 (softplus)");
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = run_acq_grad(g, type, par, fmin, y_mean, y_std))) return rc;
+    LpBatch b;
+    if ((rc = upload_lp_batch(g, Xb, nb, r_x0, s_x0, &b))) return rc;
+    launch_lp_grad(g->s, g->dAcq, g->dDacq, g->dXs, g->M, g->D, b.X, nb, b.r, b.s, transform);
     HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipMemcpyAsync(dout, g->dDacq, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipStreamSynchronize(g->s));

@@ -264,6 +264,8 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise);
 int run_predict(gp_ctx *g, int include_noise);
 int ensure_out(gp_ctx *g);
 int run_acq(gp_ctx *g, int type, double par, double fmin, double y_mean, double y_std);
+struct LpBatch { double *X = nullptr, *r = nullptr, *s = nullptr; };
+int upload_lp_batch(gp_ctx *g, const double *Xb, int nb, const double *r0, const double *s0, LpBatch *b);
 int run_acq_lp(gp_ctx *g, int type, double par, double fmin, double y_mean, double y_std, int transform, const double *Xb, int nb, const double *r0, const double *s0);
 int wi_lauum(gp_ctx *g);
 int wi_rns(gp_ctx *g);

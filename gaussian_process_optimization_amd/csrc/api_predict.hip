@@ -157,20 +157,28 @@ extern "C" int gp_acq_argbest(gp_t *g, int type, double par, double fmin, double
 }
 
 // ---- local penalisation (batch acquisition of run.py:1238-1257; GPyOpt/GPyOpt/acquisitions/LP.py) -----------
-int run_acq_lp(gp_ctx *g, int type, double par, double fmin, double y_mean, double y_std, int transform, const double *Xb, int nb, const double *r0, const double *s0) {
+// the batch centres, radii and scales of the penaliser (<= 256 rows) in a small device buffer of their own
+int upload_lp_batch(gp_ctx *g, const double *Xb, int nb, const double *r0, const double *s0, LpBatch *b) {
     if (nb < 0 || nb > 256) return fail(GP_ERR_ARG, "batch size out of range (0..256)");
     int rc;
-    if ((rc = run_acq(g, type, par, fmin, y_mean, y_std))) return rc;
-    // small batch arrays live behind the reduction scratch
-    int rcb;
-    if ((rcb = dev_realloc(&g->dLp, &g->capLp, (long)256 * (GP_MAX_D + 2)))) return rcb;
-    double *dXb = g->dLp, *dr = g->dLp + 256 * GP_MAX_D, *ds = dr + 256;
+    if ((rc = dev_realloc(&g->dLp, &g->capLp, (long)256 * (GP_MAX_D + 2)))) return rc;
+    b->X = g->dLp;
+    b->r = g->dLp + 256 * GP_MAX_D;
+    b->s = b->r + 256;
     if (nb > 0) {
-        HIPCHK(hipMemcpyAsync(dXb, Xb, sizeof(double) * nb * g->D, hipMemcpyHostToDevice, g->s));
-        HIPCHK(hipMemcpyAsync(dr, r0, sizeof(double) * nb, hipMemcpyHostToDevice, g->s));
-        HIPCHK(hipMemcpyAsync(ds, s0, sizeof(double) * nb, hipMemcpyHostToDevice, g->s));
+        HIPCHK(hipMemcpyAsync(b->X, Xb, sizeof(double) * nb * g->D, hipMemcpyHostToDevice, g->s));
+        HIPCHK(hipMemcpyAsync(b->r, r0, sizeof(double) * nb, hipMemcpyHostToDevice, g->s));
+        HIPCHK(hipMemcpyAsync(b->s, s0, sizeof(double) * nb, hipMemcpyHostToDevice, g->s));
     }
-    launch_lp(g->s, g->dAcq, g->dXs, g->M, g->D, dXb, nb, dr, ds, transform, g->dAcq);
+    return 0;
+}
+
+int run_acq_lp(gp_ctx *g, int type, double par, double fmin, double y_mean, double y_std, int transform, const double *Xb, int nb, const double *r0, const double *s0) {
+    int rc;
+    if ((rc = run_acq(g, type, par, fmin, y_mean, y_std))) return rc;
+    LpBatch b;
+    if ((rc = upload_lp_batch(g, Xb, nb, r0, s0, &b))) return rc;
+    launch_lp(g->s, g->dAcq, g->dXs, g->M, g->D, b.X, nb, b.r, b.s, transform, g->dAcq);
     return 0;
 }
 

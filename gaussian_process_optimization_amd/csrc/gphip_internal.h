@@ -156,6 +156,8 @@ void launch_set_identity_blocks(hipStream_t s, double *T, long n, int nb);
 void launch_transpose_blocks(hipStream_t s, double *dst, const double *src, long n, int nb);
 void launch_lp(hipStream_t s, const double *negacq, const double *Xs, long M, int D, const double *Xb, int nb,
                const double *r0, const double *s0, int transform, double *out);
+void launch_lp_grad(hipStream_t s, double *negacq, double *dneg, const double *Xs, long M, int D, const double *Xb, int nb,
+                    const double *r0, const double *s0, int transform);
 void launch_mask(hipStream_t s, double *v, const long long *idx, int n, double fill);
 // out[i, j] = 0.5 (sum_p alpha_p[i] alpha_p[j] - P Wi[i, j]),  i, j < N  (exact_gaussian_inference.py:70)
 void launch_dldk(hipStream_t s, double *out, long ldo, const double *alpha, long lda_, int P, const double *Wi,

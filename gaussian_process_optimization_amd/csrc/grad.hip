@@ -432,6 +432,45 @@ void launch_lp(hipStream_t s, const double *negacq, const double *Xs, long M, in
     hipLaunchKernelGGL(lp_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, negacq, Xs, M, D, Xb, nb, r0, s0,
                        transform, out);
 }
+// value and gradient of the penalised acquisition (LP.py:112-140).  in: negacq[M] = -acq(x), dneg[M, D] = -d acq / dx (the
+// outputs of acq_grad_kernel), overwritten in place by the penalised value and its gradient.  The penaliser's gradient is
+// the reference's: one scalar per (candidate, centre) summed over the batch and subtracted from every dimension.
+__global__ void lp_grad_kernel(double *negacq, double *dneg, const double *Xs, long M, int D, const double *Xb, int nb,
+                               const double *r0, const double *s0, int transform) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const double a = -negacq[i];
+    double f, scale;
+    if (transform == 1) {
+        const double sp = log1p(exp(a));
+        f = (a >= 40.0) ? log(a) : log(sp);
+        scale = 1.0 / (sp * (1.0 + exp(-a)));
+    } else {
+        f = log(a + 1e-50);
+        scale = 1.0 / a;
+    }
+    f = -f;
+    double pen = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double df = Xs[i * D + d] - Xb[k * D + d];
+            d2 = fma(df, df, d2);
+        }
+        const double nm = sqrt(d2);
+        const double z = (nm - r0[k]) / s0[k];
+        f -= log_ndtr(z);
+        const double cdf = 0.5 * erfc(-z / 1.41421356237309504880168872420970);
+        if (!(cdf < 1e-50)) pen += 1.0 / (s0[k] * 2.50662827463100050241576528481105 * cdf) * exp(-0.5 * z * z) / nm;
+    }
+    negacq[i] = f;
+    for (int d = 0; d < D; ++d) dneg[i * D + d] = scale * dneg[i * D + d] - pen;
+}
+void launch_lp_grad(hipStream_t s, double *negacq, double *dneg, const double *Xs, long M, int D, const double *Xb, int nb,
+                    const double *r0, const double *s0, int transform) {
+    hipLaunchKernelGGL(lp_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, negacq, dneg, Xs, M, D, Xb, nb, r0,
+                       s0, transform);
+}
 __global__ void mask_kernel(double *v, const long long *idx, int n, double fill) {
     const int i = threadIdx.x;
     if (i < n) v[idx[i]] = fill;

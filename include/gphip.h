@@ -193,6 +193,14 @@ int gp_acq_grad(gp_t *gp, int type, double par, double fmin, double y_mean, doub
  * nb = 0 gives the un-penalised log acquisition.  out[M] as the reference returns it (to be minimised). */
 int gp_acq_lp(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std, int transform,
               const double *Xb, int nb, const double *r_x0, const double *s_x0, double *out);
+/* AcquisitionLP.acquisition_function_withGradients (LP.py:112-140) on the resident candidates: out[M] as gp_acq_lp,
+ * dout[M,D] = scale * d(-acq)/dx - sum_k pen_k, with scale = 1 / acq (transform 0) or 1 / (softplus(acq) (1 + exp(-acq)))
+ * (transform 1) and pen_k = exp(-z^2/2) / (s_x0[k] sqrt(2 pi) Phi(z) |x - Xb_k|), z = (|x - Xb_k| - r_x0[k]) / s_x0[k],
+ * taken as 0 where Phi(z) < 1e-50.  The reference's _d_hammer_function (LP.py:91-103) sums that SCALAR over the batch and
+ * subtracts it from every input dimension (the direction (x - Xb_k) / |x - Xb_k| is missing there); reproduced as is so that
+ * an L-BFGS run over this function follows the reference's. */
+int gp_acq_lp_grad(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std, int transform,
+                   const double *Xb, int nb, const double *r_x0, const double *s_x0, double *out, double *dout);
 /* arg-best of the same vector, skipping the rows listed in exclude (run.py:1249-1252). */
 int gp_acq_lp_argbest(gp_t *gp, int type, double par, double fmin, double y_mean, double y_std, int transform,
                       const double *Xb, int nb, const double *r_x0, const double *s_x0, int sense,

@@ -260,7 +260,7 @@ def test_local_penalization_matches_reference_formulas(base):
     v = lp.acquisition_function(table)
     ref = O.lp_penalized_acquisition(-fn0(table), table, Xb, r0, s0, tr)
     np.testing.assert_allclose(v, ref, rtol=1e-6, atol=1e-8)
-    host = lp._penalized_acquisition(table, gm, Xb, lp.r_x0, lp.s_x0)      # reference formulas on device predictions
+    host = lp._score_on_host(table)      # reference formulas on device predictions
     np.testing.assert_allclose(v, host, rtol=1e-9, atol=1e-9)
     # arg-best with exclusion == masked argmax of the reference vector (run.py:1249-1252)
     taken = [int(np.argmax(v)), 17]

@@ -71,7 +71,7 @@ extern "C" int gp_comm_allgather_best(gp_t *g, double val, int64_t idx, double *
     NCCLCHK(ncclAllGather(send, recv, 2, ncclDouble, g->comm, g->s));
     std::vector<double> out(2 * g->nranks);
     HIPCHK(hipMemcpyAsync(out.data(), recv, 16 * g->nranks, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     for (int r = 0; r < g->nranks; ++r) {
         vals[r] = out[2 * r];
         memcpy(&idxs[r], &out[2 * r + 1], 8);
@@ -122,7 +122,7 @@ extern "C" int gp_comm_bcast_fit(gp_t *g, int root) {
     NCCLCHK(ncclBroadcast(dRec, dRec, GP_FIT_RECORD_LEN, ncclDouble, root, g->comm, g->s));
     NCCLCHK(ncclGroupEnd());
     HIPCHK(hipMemcpyAsync(rec, dRec, sizeof rec, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     apply_fit_record(g, rec);
     return 0;
 }
@@ -174,7 +174,7 @@ extern "C" int gp_comm_allgather_topk(gp_t *g, int k, const double *vals, const 
     NCCLCHK(ncclAllGather(send, recv, 2 * (size_t)k, ncclDouble, g->comm, g->s));
     std::vector<double> out(2 * (size_t)k * g->nranks);
     HIPCHK(hipMemcpyAsync(out.data(), recv, 16 * (size_t)k * g->nranks, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     for (size_t r = 0; r < (size_t)k * g->nranks; ++r) {
         all_vals[r] = out[2 * r];
         memcpy(&all_idxs[r], &out[2 * r + 1], 8);

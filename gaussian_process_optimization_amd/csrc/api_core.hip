@@ -14,6 +14,22 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// first failed launch / stream operation of the calling thread since the last report (gphip_internal.h)
+static thread_local bool g_note_set = false;
+static thread_local std::string g_note_msg;
+void gp_note_hip(hipError_t e, const char *what, const char *file, int line) {
+    if (e == hipSuccess || g_note_set) return;
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s -> %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_note_msg = buf;
+    g_note_set = true;
+}
+int gp_pending_error() {
+    if (!g_note_set) return 0;
+    g_note_set = false;
+    return fail(GP_ERR_HIP, "%s", g_note_msg.c_str());
+}
+
 static std::mutex g_ds_mu;
 static std::map<int, DevStreams> g_ds;
 static std::set<gp_ctx *> g_live;  // contexts created and not yet destroyed
@@ -112,11 +128,11 @@ int phase_begin(gp_ctx *g, const char *name, double flops, double bytes) {
         hipEventCreate(&p.e1);
         p.used = true;
     }
-    hipEventRecord(p.e0, g->s);
+    GP_NOTE(hipEventRecord(p.e0, g->s));
     return g->nphases++;
 }
 void phase_end(gp_ctx *g, int id) {
-    if (id >= 0) hipEventRecord(g->phases[id].e1, g->s);
+    if (id >= 0) GP_NOTE(hipEventRecord(g->phases[id].e1, g->s));
 }
 
 // ---- GEMM wrapper with accounting ---------------------------------------------------------------
@@ -156,7 +172,7 @@ void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const double 
         }
         e0 = g->gemm_events[g->gemm_ev_used++];
         e1 = g->gemm_events[g->gemm_ev_used++];
-        hipEventRecord(e0, s);
+        GP_NOTE(hipEventRecord(e0, s));
         g->gemm_tiles.push_back(n);
         g->gemm_K.push_back((o.k_tri || o.k_end_tri) ? -K : K);
     }
@@ -175,7 +191,7 @@ void gemm(gp_ctx *g, hipStream_t s, int mode, double *C, long ldc, const double 
     }
     launch_gemm_nt(s, mode, C, ldc, A, lda, B, ldb, b_mul, K, ts, oo);
     if (timed) {
-        hipEventRecord(e1, s);
+        GP_NOTE(hipEventRecord(e1, s));
         g->gemm_launches++;
         g->gemm_flops += 2.0 * GP_TILE * GP_TILE * (double)K * (double)n * ((o.k_tri || o.k_end_tri) ? 0.5 : 1.0);
     }
@@ -387,6 +403,9 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "emulate_fp64")) {
         g->emulate_fp64 = value ? 1 : 0;
         g->predicted = false;
+    } else if (!strcmp(name, "debug_potrf_lds")) {
+        if (value < 0 || value > (1 << 20)) return fail(GP_ERR_ARG, "debug_potrf_lds out of range");
+        potrf_set_debug_lds((int)value);   // process-wide test hook: forces refused diagonal-tile launches (tests/test_gpu_round4.py)
     } else if (!strcmp(name, "mc_max")) {
         if (value < GP_TILE) return fail(GP_ERR_ARG, "mc_max < 128");
         g->mc_max = round_up(value, GP_TILE);
@@ -399,11 +418,11 @@ extern "C" int gp_synchronize(gp_t *g) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
     GP_DEAD_CHECK(g);
     HIPCHK(hipSetDevice(g->device));
-    HIPCHK(hipStreamSynchronize(g->s_panel));
-    if (g->s_bulk) HIPCHK(hipStreamSynchronize(g->s_bulk));
-    if (g->s_inv) HIPCHK(hipStreamSynchronize(g->s_inv));
-    if (g->s_pred) HIPCHK(hipStreamSynchronize(g->s_pred));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s_panel);
+    if (g->s_bulk) GP_SYNC(g->s_bulk);
+    if (g->s_inv) GP_SYNC(g->s_inv);
+    if (g->s_pred) GP_SYNC(g->s_pred);
+    GP_SYNC(g->s);
     return 0;
 }
 
@@ -413,7 +432,7 @@ extern "C" int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N,
     if (N < 1 || D < 1 || D > GP_MAX_D || P < 1 || P > GP_MAX_RHS)
         return fail(GP_ERR_ARG, "bad shape N=%ld D=%d P=%d (D <= %d, P <= %d)", (long)N, D, P, GP_MAX_D, GP_MAX_RHS);
     HIPCHK(hipSetDevice(g->device));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     const long Npad = round_up(N, GP_TILE);
     if (Npad > g->capN || P > g->capP || !g->dA) {
         double **bufs[] = {&g->dX, &g->dY, &g->dA, &g->dInvL, &g->dAlpha, &g->dW, &g->dMu};
@@ -442,7 +461,7 @@ extern "C" int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N,
     g->P = P;
     HIPCHK(hipMemcpyAsync(g->dX, X, sizeof(double) * N * D, hipMemcpyHostToDevice, g->s));
     HIPCHK(hipMemcpyAsync(g->dY, Y, sizeof(double) * N * P, hipMemcpyHostToDevice, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     g->have_data = true;
     g->fitted = false;
     g->fmin_valid = false;
@@ -586,7 +605,7 @@ extern "C" int gp_kernel_matrix(gp_t *g, double *K) {
     HIPCHK(hipSetDevice(g->device));
     const long N = g->N;
     launch_kbuild(g->s, g->dA, g->Npad, g->dX, N, g->Npad, g->kp, 0.0, 1);
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     HIPCHK(hipMemcpy2D(K, sizeof(double) * N, g->dA, sizeof(double) * g->Npad, sizeof(double) * N, N,
                        hipMemcpyDeviceToHost));
     g->fitted = false;  // dA was overwritten
@@ -611,7 +630,7 @@ extern "C" int gp_cross_kernel_matrix(gp_t *g, const double *X2, int64_t M2, dou
     if ((rc = dev_realloc(&g->dK2, &g->capK2, Npad * M2pad))) return rc;
     HIPCHK(hipMemcpyAsync(g->dX2, X2, sizeof(double) * M2 * g->D, hipMemcpyHostToDevice, g->s));
     launch_cross_k(g->s, g->dK2, M2pad, g->dX, N, Npad, g->dX2, M2, M2pad, g->kp);
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     HIPCHK(hipMemcpy2D(K, sizeof(double) * M2, g->dK2, sizeof(double) * M2pad, sizeof(double) * M2, N, hipMemcpyDeviceToHost));
     return 0;
 }

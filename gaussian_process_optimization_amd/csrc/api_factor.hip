@@ -13,8 +13,8 @@ void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, in
     hipStream_t s = g->s;
     if (side_inv) {
         hipEvent_t e0 = la_event(g, EV_MISC, 0);
-        hipEventRecord(e0, s);
-        hipStreamWaitEvent(g->s_inv, e0, 0);
+        GP_NOTE(hipEventRecord(e0, s));
+        GP_NOTE(hipStreamWaitEvent(g->s_inv, e0, 0));
     }
     for (int J0 = 0; J0 < nt; J0 += W) {
         const int J1 = std::min(J0 + W, nt);
@@ -30,8 +30,8 @@ void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, in
         }
         if (side_inv) {
             hipEvent_t eF = la_event(g, EV_CHAIN, J0 / W);
-            hipEventRecord(eF, s);
-            hipStreamWaitEvent(g->s_inv, eF, 0);
+            GP_NOTE(hipEventRecord(eF, s));
+            GP_NOTE(hipStreamWaitEvent(g->s_inv, eF, 0));
             build_panel_inv_one(g, g->s_inv, J0 / W, W, nt);
         }
         // trailing update with the whole panel (K = W * 128): the dense contraction on MFMA
@@ -41,8 +41,8 @@ void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, in
     }
     if (side_inv) {
         hipEvent_t ei = la_event(g, EV_MISC, 4);
-        hipEventRecord(ei, g->s_inv);
-        hipStreamWaitEvent(s, ei, 0);
+        GP_NOTE(hipEventRecord(ei, g->s_inv));
+        GP_NOTE(hipStreamWaitEvent(s, ei, 0));
     }
 }
 
@@ -100,9 +100,9 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
     hipStream_t sp = g->s_panel, sb = g->s_bulk;
     // fork
     hipEvent_t e0 = la_event(g, EV_MISC, 0);
-    hipEventRecord(e0, g->s);
-    hipStreamWaitEvent(sp, e0, 0);
-    hipStreamWaitEvent(sb, e0, 0);
+    GP_NOTE(hipEventRecord(e0, g->s));
+    GP_NOTE(hipStreamWaitEvent(sp, e0, 0));
+    GP_NOTE(hipStreamWaitEvent(sb, e0, 0));
     const long PB = (long)W * GP_TILE;
     const int nJu = (nt + W - 1) / W;
     // Every inverted diagonal panel (alpha, the candidate solve and Ky^-1 all need them) is built on the side stream as soon
@@ -110,9 +110,9 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
     // its own, 2W - 1 short launches in series, it held the main stream for 0.3 ms between the factor and its first consumer).
     if ((rc = dev_realloc(&g->dInvP, &g->capInvP, (long)nJu * PB * PB))) return rc;
     if ((rc = dev_realloc(&g->dInvPw, &g->capInvPw, (long)nJu * PB * PB))) return rc;
-    hipStreamWaitEvent(g->s_inv, e0, 0);
+    GP_NOTE(hipStreamWaitEvent(g->s_inv, e0, 0));
     if (pp.on) {
-        hipStreamWaitEvent(g->s_pred, e0, 0);
+        GP_NOTE(hipStreamWaitEvent(g->s_pred, e0, 0));
         if (pp.init) pp.init(g->s_pred);
     }
     int next_pred = 0;
@@ -143,7 +143,7 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
     hipStream_t sfar = g->s_pred;
     std::vector<char> far_issued(nJ / std::max(1, Gf) + 2, 0);
     int mid_Jg = -1, mid_end = 0, mid_first = 0, mid_base = 0, mid_next = 0;
-    if (Gf > 1) hipStreamWaitEvent(sfar, e0, 0);
+    if (Gf > 1) GP_NOTE(hipStreamWaitEvent(sfar, e0, 0));
     for (int J = 0; J < nJ; ++J) {
         const int J0 = pb[J], J1 = pb[J + 1], J2 = pb[J + 2];
         bool bulk_recorded = false;
@@ -156,12 +156,12 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
                      TileSet{0, R1, j + 1, J1, 1});
         }
         hipEvent_t eF = la_event(g, EV_CHAIN, J);
-        hipEventRecord(eF, sp);
+        GP_NOTE(hipEventRecord(eF, sp));
         const int K = (J1 - J0) * GP_TILE;
-        hipStreamWaitEvent(g->s_inv, eF, 0);
+        GP_NOTE(hipStreamWaitEvent(g->s_inv, eF, 0));
         build_panel_inv_one(g, g->s_inv, J, W, nt);
         if (pp.on) {
-            if (J < pstages) hipEventRecord(la_event(g, EV_INVP, J), g->s_inv);
+            if (J < pstages) GP_NOTE(hipEventRecord(la_event(g, EV_INVP, J), g->s_inv));
             // Two concurrent MFMA-bound launches run slower than one after the other (measured 51 vs 63 TFLOP/s), and
             // the candidate stream is CU-masked like the trailing update (the diagonal-tile workgroup needs an empty
             // CU), which costs it 1/8 of the chip.  So only the first `pipe_stages` stages ride here, released once
@@ -173,8 +173,8 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
                     const int Q = next_pred, Q0 = Q * W, Q1 = std::min(Q0 + W, nt);
                     const int KQ = (Q1 - Q0) * GP_TILE;
                     const int prow = pp.trapezoid ? std::min(pp.mt, Q1) : pp.mt;
-                    hipStreamWaitEvent(g->s_pred, la_event(g, EV_CHAIN, J), 0);
-                    hipStreamWaitEvent(g->s_pred, la_event(g, EV_INVP, Q), 0);
+                    GP_NOTE(hipStreamWaitEvent(g->s_pred, la_event(g, EV_CHAIN, J), 0));
+                    GP_NOTE(hipStreamWaitEvent(g->s_pred, la_event(g, EV_INVP, Q), 0));
                     GemmOpt o;
                     o.k_end_tri = 1;
                     o.b_sub = Q0;
@@ -189,13 +189,13 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
         if (J1 >= nt) break;
         // the look-ahead update is on the critical path: enqueue it before the trailing update so that its
         // workgroups reach the dispatcher first once bulk(J-1) has drained
-        if (J >= 1) hipStreamWaitEvent(sp, la_event(g, EV_BULK, J - 1), 0);
+        if (J >= 1) GP_NOTE(hipStreamWaitEvent(sp, la_event(g, EV_BULK, J - 1), 0));
         // (emulated: the look-ahead panel's columns took everything the residue accumulator holds for them -- panels
         // 0 .. J-1 -- on the bulk stream, before bulk(J-1) was recorded)
         gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
              TileSet{0, R1, J1, J2, 1});
         if (J2 < nt) {
-            hipStreamWaitEvent(sb, eF, 0);
+            GP_NOTE(hipStreamWaitEvent(sb, eF, 0));
             if (emu) {
                 rns_convert_panel(g, sb, rg, J, rflag);
                 // the right-hand-side tile row rides in fp64
@@ -235,22 +235,22 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
                     // BEFORE mid so that the chain does not wait for it.  The integers summed are those of Gf = 1.
                     const int gi = J / Gf, Jg = gi * Gf;
                     const int first = gi == 0 ? 1 : 0;
-                    hipEventRecord(la_event(g, EV_CONV, J), sb);
+                    GP_NOTE(hipEventRecord(la_event(g, EV_CONV, J), sb));
                     rlaunch(sb, Jg, pbi(J + 2), pbi(J + 3), first);
                     rebuild_next();
-                    hipEventRecord(la_event(g, EV_BULK, J), sb);
+                    GP_NOTE(hipEventRecord(la_event(g, EV_BULK, J), sb));
                     bulk_recorded = true;
                     if (J % Gf == Gf - 1) {
-                        if (gi >= 1 && far_issued[gi - 1]) hipStreamWaitEvent(sb, la_event(g, EV_FAR, gi - 1), 0);
+                        if (gi >= 1 && far_issued[gi - 1]) GP_NOTE(hipStreamWaitEvent(sb, la_event(g, EV_FAR, gi - 1), 0));
                         mid_Jg = Jg;            // the slices of mid(g): column panel mid_base + k at iteration J + k
                         mid_end = J1;
                         mid_first = first;
                         mid_base = J + 3;
                         mid_next = 0;
                         if (pbi(J + 3 + Gf) < nt) {
-                            hipStreamWaitEvent(sfar, la_event(g, EV_CONV, J), 0);
+                            GP_NOTE(hipStreamWaitEvent(sfar, la_event(g, EV_CONV, J), 0));
                             rlaunch(sfar, Jg, pbi(J + 3 + Gf), nt, first);
-                            hipEventRecord(la_event(g, EV_FAR, gi), sfar);
+                            GP_NOTE(hipEventRecord(la_event(g, EV_FAR, gi), sfar));
                             far_issued[gi] = true;
                         }
                     }
@@ -263,29 +263,29 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
                 gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
                      TileSet{0, R1, J2, nt, 1});
             }
-            if (!bulk_recorded) hipEventRecord(la_event(g, EV_BULK, J), sb);
+            if (!bulk_recorded) GP_NOTE(hipEventRecord(la_event(g, EV_BULK, J), sb));
         }
     }
     // join
     hipEvent_t ep = la_event(g, EV_MISC, 1), eb = la_event(g, EV_MISC, 2);
-    hipEventRecord(ep, sp);
-    hipEventRecord(eb, sb);
-    hipStreamWaitEvent(g->s, ep, 0);
-    hipStreamWaitEvent(g->s, eb, 0);
+    GP_NOTE(hipEventRecord(ep, sp));
+    GP_NOTE(hipEventRecord(eb, sb));
+    GP_NOTE(hipStreamWaitEvent(g->s, ep, 0));
+    GP_NOTE(hipStreamWaitEvent(g->s, eb, 0));
     if (Gf > 1) {   // (every far launch ends before the factor is complete: mid of the next group waits for it; join anyway)
         hipEvent_t ef = la_event(g, EV_MISC, 7);
-        hipEventRecord(ef, sfar);
-        hipStreamWaitEvent(g->s, ef, 0);
+        GP_NOTE(hipEventRecord(ef, sfar));
+        GP_NOTE(hipStreamWaitEvent(g->s, ef, 0));
     }
     g->pipe_done = pstages;
     if (pp.on) {
         hipEvent_t eq = la_event(g, EV_MISC, 3);
-        hipEventRecord(eq, g->s_pred);
-        hipStreamWaitEvent(g->s, eq, 0);
+        GP_NOTE(hipEventRecord(eq, g->s_pred));
+        GP_NOTE(hipStreamWaitEvent(g->s, eq, 0));
     }
     hipEvent_t ei = la_event(g, EV_MISC, 4);
-    hipEventRecord(ei, g->s_inv);
-    hipStreamWaitEvent(g->s, ei, 0);
+    GP_NOTE(hipEventRecord(ei, g->s_inv));
+    GP_NOTE(hipStreamWaitEvent(g->s, ei, 0));
     g->invp_W = W;
     g->invp_valid = true;   // (fit_impl drops it again when the attempt turns out not positive definite)
     return la_events_ok(g);   // (an error return makes fit_impl quiesce every stream before it reports)
@@ -400,7 +400,7 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
         }
         phase_end(g, ph);
         HIPCHK(hipMemcpyAsync(&info, g->dInfo, sizeof(int), hipMemcpyDeviceToHost, g->s));
-        HIPCHK(hipStreamSynchronize(g->s));
+        GP_SYNC(g->s);
         if (g->emulate_fp64 && !g->emu_off_call && info == 0) {
             int bad = 0;
             HIPCHK(hipMemcpy(&bad, g->dInfo + 2, sizeof(int), hipMemcpyDeviceToHost));
@@ -436,7 +436,7 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     auto alpha_lml = [&](hipStream_t st) {
         launch_logdet(st, g->dA, lda, N, g->dScal);
         launch_trsv_backward(st, g->dA, lda, g->dInvP, g->invp_W, Npad, g->dA + Npad * lda, lda, P, g->dAlpha, g->dW);
-        hipLaunchKernelGGL(dot_ay_kernel, dim3(P), dim3(1024), 0, st, g->dAlpha, Npad, g->dY, N, P, g->dScal + 8);
+        GP_LAUNCH(dot_ay_kernel, dim3(P), dim3(1024), 0, st, g->dAlpha, Npad, g->dY, N, P, g->dScal + 8);
     };
     if (pipe) {
         const int W = std::min(g->panel_tiles, nt_);
@@ -446,14 +446,14 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
             int rci = ensure_panel_inv(g);
             if (rci) return rci;
             hipEvent_t eI = la_event(g, EV_MISC, 5);
-            if (g->s_inv && g->side_alpha) hipEventRecord(eI, g->s);
+            if (g->s_inv && g->side_alpha) GP_NOTE(hipEventRecord(eI, g->s));
             // the long launches first: the 45 short launches of alpha / log det take the host 0.7 ms to enqueue, during which
             // the main stream sat empty when they went first
             solve_rows(g, g->dT, g->dT2, (int)(mcpad / GP_TILE), pipe == 2 ? 1 : 0, g->pipe_done);
             if (g->s_inv && g->side_alpha) {
-                hipStreamWaitEvent(g->s_inv, eI, 0);
+                GP_NOTE(hipStreamWaitEvent(g->s_inv, eI, 0));
                 alpha_lml(g->s_inv);
-                hipEventRecord(la_event(g, EV_MISC, 6), g->s_inv);
+                GP_NOTE(hipEventRecord(la_event(g, EV_MISC, 6), g->s_inv));
                 side_alpha = true;
             }
             phase_end(g, phr);
@@ -467,7 +467,7 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
 
     int ph = phase_begin(g, "alpha_lml", 2.0 * (double)N * N * P, 8.0 * (double)N * N / 2);
     if (side_alpha) {
-        hipStreamWaitEvent(g->s, la_event(g, EV_MISC, 6), 0);
+        GP_NOTE(hipStreamWaitEvent(g->s, la_event(g, EV_MISC, 6), 0));
     } else {
         int rci = ensure_panel_inv(g);
         if (rci) return rci;
@@ -482,7 +482,7 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     }
     std::vector<double> sc(8 + P);
     HIPCHK(hipMemcpyAsync(sc.data(), g->dScal, sizeof(double) * (8 + P), hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     double fit = 0.0;
     for (int p = 0; p < P; ++p) fit += sc[8 + p];
     g->logdet = sc[0];
@@ -535,6 +535,6 @@ extern "C" int gp_fit_predict(gp_t *g, int maxtries, int include_noise, double *
     if (jitter_used) *jitter_used = g->jitter;
     if (mean) HIPCHK(hipMemcpyAsync(mean, g->dMean, sizeof(double) * g->M * g->P, hipMemcpyDeviceToHost, g->s));
     if (var) HIPCHK(hipMemcpyAsync(var, g->dVar, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     return 0;
 }

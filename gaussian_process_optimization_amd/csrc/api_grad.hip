@@ -30,7 +30,7 @@ int lml_grad_impl(gp_ctx *g, double *dvariance, double *dlengthscale, double *dn
     const int npass = g->ard ? (D + GP_GRAD_CH - 1) / GP_GRAD_CH : 1;
     HIPCHK(hipMemcpyAsync(host.data(), g->dScal + 64, sizeof(double) * GP_GRAD_NACC * npass, hipMemcpyDeviceToHost,
                           g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     (void)ntile;
     *dvariance = host[0] / g->kp.variance;  // stationary.py:224
     *dnoise = host[1];                      // gaussian.py:78-79
@@ -123,7 +123,7 @@ extern "C" int gp_predict_grad(gp_t *g, double *dmdx, double *dvdx) {
     if ((rc = run_predict_grad(g))) return rc;
     HIPCHK(hipMemcpyAsync(dmdx, g->dDm, sizeof(double) * g->M * g->D * g->P, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipMemcpyAsync(dvdx, g->dDv, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     return 0;
 }
 
@@ -137,7 +137,7 @@ extern "C" int gp_acq_grad(gp_t *g, int type, double par, double fmin, double y_
     if ((rc = run_acq_grad(g, type, par, fmin, y_mean, y_std))) return rc;
     HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipMemcpyAsync(dout, g->dDacq, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     return 0;
 }
 
@@ -171,7 +171,7 @@ extern "C" int gp_acq_lp_grad(gp_t *g, int type, double par, double fmin, double
     launch_lp_grad(g->s, g->dAcq, g->dDacq, g->dXs, g->M, g->D, b.X, nb, b.r, b.s, transform);
     HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipMemcpyAsync(dout, g->dDacq, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     return 0;
 }
 
@@ -187,7 +187,7 @@ extern "C" int gp_get_dl_dk(gp_t *g, double *dL_dK) {
     if ((rc = ensure_wi(g))) return rc;  // leaves dT free (Npad x Npad)
     const long N = g->N, Npad = g->Npad;
     launch_dldk(g->s, g->dT, Npad, g->dAlpha, Npad, g->P, g->dWi, Npad, N);
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     HIPCHK(hipMemcpy2D(dL_dK, sizeof(double) * N, g->dT, sizeof(double) * Npad, sizeof(double) * N, N,
                        hipMemcpyDeviceToHost));
     g->predicted = false;  // dT was reused

@@ -34,6 +34,16 @@ int fail(int code, const char *fmt, ...);
         ncclResult_t r_ = (x);                                                                       \
         if (r_ != ncclSuccess) return fail(GP_ERR_RCCL, "%s -> %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
+// Drain a stream, then report (and clear) what gp_note_hip recorded since the last report: the point where an entry point's
+// results are about to be read.
+int gp_pending_error();
+#define GP_SYNC(stream)                                                                            \
+    do {                                                                                            \
+        hipError_t e_ = hipStreamSynchronize(stream);                                               \
+        int p_ = gp_pending_error();                                                                \
+        if (p_) return p_;                                                                          \
+        if (e_ != hipSuccess) return fail(GP_ERR_HIP, "hipStreamSynchronize(%s) -> %s (%s:%d)", #stream, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
 #define GP_ERR_RANGE (-1000)   // internal: an operand of the residue path left the fixed-point range (the caller repeats in fp64)
 #define GP_DEAD_CHECK(g)                                                                            \
     do {                                                                                            \

@@ -9,7 +9,7 @@ extern "C" int gp_set_candidates(gp_t *g, const double *Xs, int64_t M) {
     if (!g->have_data) return fail(GP_ERR_STATE, "gp_set_data first");
     if (M < 1) return fail(GP_ERR_ARG, "M < 1");
     HIPCHK(hipSetDevice(g->device));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     int rc;
     if ((rc = dev_realloc(&g->dXs, &g->capM, (long)M * g->D))) return rc;
     HIPCHK(hipMemcpy(g->dXs, Xs, sizeof(double) * M * g->D, hipMemcpyHostToDevice));
@@ -85,7 +85,7 @@ extern "C" int gp_predict(gp_t *g, int include_noise, double *mean, double *var)
     if ((rc = run_predict(g, include_noise))) return rc;
     if (mean) HIPCHK(hipMemcpyAsync(mean, g->dMean, sizeof(double) * g->M * g->P, hipMemcpyDeviceToHost, g->s));
     if (var) HIPCHK(hipMemcpyAsync(var, g->dVar, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     return 0;
 }
 
@@ -103,7 +103,7 @@ extern "C" int gp_fmin(gp_t *g, double *fmin) {
         launch_argbest(g->s, g->dMu, g->N, -1, g->dRedV + 256, g->dRedI + 256, g->dRedV, g->dRedI);
         double v = 0.0;
         HIPCHK(hipMemcpyAsync(&v, g->dRedV + 256, sizeof(double), hipMemcpyDeviceToHost, g->s));
-        HIPCHK(hipStreamSynchronize(g->s));
+        GP_SYNC(g->s);
         g->fmin = v;
         g->fmin_valid = true;
     }
@@ -131,7 +131,7 @@ extern "C" int gp_acq(gp_t *g, int type, double par, double fmin, double y_mean,
     int rc;
     if ((rc = run_acq(g, type, par, fmin, y_mean, y_std))) return rc;
     HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     return 0;
 }
 
@@ -150,7 +150,7 @@ extern "C" int gp_acq_argbest(gp_t *g, int type, double par, double fmin, double
     long long i = 0;
     HIPCHK(hipMemcpyAsync(&v, g->dRedV + 256, sizeof(double), hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipMemcpyAsync(&i, g->dRedI + 256, sizeof(long long), hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     *val = v;
     *idx = (int64_t)i;
     return 0;
@@ -192,7 +192,7 @@ extern "C" int gp_acq_lp(gp_t *g, int type, double par, double fmin, double y_me
     int rc;
     if ((rc = run_acq_lp(g, type, par, fmin, y_mean, y_std, transform, Xb, nb, r_x0, s_x0))) return rc;
     HIPCHK(hipMemcpyAsync(out, g->dAcq, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     return 0;
 }
 
@@ -220,7 +220,7 @@ extern "C" int gp_acq_lp_argbest(gp_t *g, int type, double par, double fmin, dou
     long long i = 0;
     HIPCHK(hipMemcpyAsync(&v, g->dRedV + 256, sizeof(double), hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipMemcpyAsync(&i, g->dRedI + 256, sizeof(long long), hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     *val = v;
     *idx = (int64_t)i;
     return 0;
@@ -244,7 +244,7 @@ extern "C" int gp_predict_full_cov(gp_t *g, int include_noise, double *mean, dou
     gemm(g, g->s, 1, g->dCov, Mpad, g->dT2, Npad, g->dT2, Npad, 1, (int)Npad, TileSet{0, mt, 0, mt, 0});
     if (include_noise) launch_add_diag(g->s, g->dCov, Mpad, M, g->noise);  // gaussian.py:104-105
     if (mean) HIPCHK(hipMemcpyAsync(mean, g->dMean, sizeof(double) * M * g->P, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     HIPCHK(hipMemcpy2D(cov, sizeof(double) * M, g->dCov, sizeof(double) * Mpad, sizeof(double) * M, M,
                        hipMemcpyDeviceToHost));
     return 0;
@@ -277,7 +277,7 @@ extern "C" int gp_acq_topk(gp_t *g, int type, double par, double fmin, double y_
     std::vector<long long> hi(kk);
     HIPCHK(hipMemcpyAsync(val, dv, sizeof(double) * kk, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipMemcpyAsync(hi.data(), di, sizeof(long long) * kk, hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     for (int j = 0; j < kk; ++j) idx[j] = (int64_t)hi[j];
     for (int j = kk; j < k; ++j) {  // fewer candidates than k: the tail is marked empty
         idx[j] = -1;
@@ -332,7 +332,7 @@ extern "C" int gp_posterior_samples(gp_t *g, int include_noise, const double *Z,
         HIPCHK(hipMemsetAsync(g->dInfo, 0, sizeof(int) * 4, g->s));
         factor_buf(g, C, Mpad, mt, mt, invL, g->dInfo);
         HIPCHK(hipMemcpyAsync(&info, g->dInfo, sizeof(int), hipMemcpyDeviceToHost, g->s));
-        HIPCHK(hipStreamSynchronize(g->s));
+        GP_SYNC(g->s);
         if (g->emulate_fp64 && info == 0) {
             int bad = 0;
             HIPCHK(hipMemcpy(&bad, g->dInfo + 2, sizeof(int), hipMemcpyDeviceToHost));
@@ -356,7 +356,7 @@ extern "C" int gp_posterior_samples(gp_t *g, int include_noise, const double *Z,
     if (mean) HIPCHK(hipMemcpyAsync(mean, g->dMean, sizeof(double) * M * g->P, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipMemcpy2DAsync(dev, sizeof(double) * M, Dv, sizeof(double) * Mpad, sizeof(double) * M, S,
                             hipMemcpyDeviceToHost, g->s));
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     if (jitter_used) *jitter_used = jitter;
     g->predicted = false;  // dT was used as workspace
     return 0;

@@ -20,10 +20,10 @@ void rns_gemm(gp_ctx *g, hipStream_t s, const signed char *A, long lda, long a_p
         long blocks = 0;
         for (int c = c0; c < c1; ++c) blocks += tri ? std::max(0, mt - c) : mt;
         g->rns_ops += 2.0 * 65536.0 * (double)K * (double)blocks * GP_RNS_T;
-        hipEventRecord(e0, s);
+        GP_NOTE(hipEventRecord(e0, s));
     }
     launch_rns_gemm256(s, A, lda, a_plane, B, ldb, b_plane, R, mt_all, nt_all, mt, c0, c1, K, first, tri);
-    if (e1) hipEventRecord(e1, s);
+    if (e1) GP_NOTE(hipEventRecord(e1, s));
 }
 
 int rns_prepare(gp_ctx *g, double jitter, RnsGeom *r) {
@@ -50,7 +50,7 @@ int rns_prepare(gp_ctx *g, double jitter, RnsGeom *r) {
         int rc = byte_realloc(&g->dLr, &g->capLr, need);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(g->dLr, 0, (size_t)need, g->s));
-        HIPCHK(hipStreamSynchronize(g->s));
+        GP_SYNC(g->s);
         g->lr_valid = false;
     }
     const int nJ = (nt + W - 1) / W;
@@ -170,7 +170,7 @@ int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt, const RnsSolveOpt &o
     }
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    GP_SYNC(s);
     if (bad) return GP_ERR_RANGE;   // (internal: the caller repeats the solve in true fp64)
     return 0;
 }

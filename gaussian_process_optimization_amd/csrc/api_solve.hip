@@ -176,7 +176,7 @@ extern "C" int gp_get_woodbury_inv(gp_t *g, double *Wi) {
     HIPCHK(hipSetDevice(g->device));
     int rc;
     if ((rc = ensure_wi(g))) return rc;
-    HIPCHK(hipStreamSynchronize(g->s));
+    GP_SYNC(g->s);
     HIPCHK(hipMemcpy2D(Wi, sizeof(double) * g->N, g->dWi, sizeof(double) * g->Npad, sizeof(double) * g->N, g->N,
                        hipMemcpyDeviceToHost));
     return 0;

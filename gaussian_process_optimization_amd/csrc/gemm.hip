@@ -363,46 +363,46 @@ void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *
         const long np = (long)(ts.r1 - ts.r0) * ((ts.c1 - ts.c0 + 1) / 2);
         dim3 grid((unsigned)(4 * np), (unsigned)o.batch);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_nt_kernel<0, 64, 2, true>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<0, 64, 2, true>), grid, dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, 64, 2, true>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<1, 64, 2, true>), grid, dim3(256), 0, s, a);
     } else if (o.rows64 == 32) {
         dim3 grid((unsigned)(4 * n), (unsigned)o.batch);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 2, false, 32>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<0, 128, 2, false, 32>), grid, dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 2, false, 32>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<1, 128, 2, false, 32>), grid, dim3(256), 0, s, a);
     } else if (o.rows64) {
         dim3 grid((unsigned)(2 * n), (unsigned)o.batch);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 2, false, 64>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<0, 128, 2, false, 64>), grid, dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 2, false, 64>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<1, 128, 2, false, 64>), grid, dim3(256), 0, s, a);
     } else if (o.waves8 && o.pair) {
         const long np = (long)(ts.r1 - ts.r0) * ((ts.c1 - ts.c0 + 1) / 2);
         dim3 grid((unsigned)np, (unsigned)o.batch);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 4, true>), grid, dim3(512), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<0, 128, 4, true>), grid, dim3(512), 0, s, a);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 4, true>), grid, dim3(512), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<1, 128, 4, true>), grid, dim3(512), 0, s, a);
     } else if (o.small) {
         dim3 grid((unsigned)(4 * n), (unsigned)o.batch);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_nt_kernel<0, 64, 2>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<0, 64, 2>), grid, dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, 64, 2>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<1, 64, 2>), grid, dim3(256), 0, s, a);
     } else if (o.waves8) {
         dim3 grid((unsigned)n, (unsigned)o.batch);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 4>), grid, dim3(512), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<0, 128, 4>), grid, dim3(512), 0, s, a);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 4>), grid, dim3(512), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<1, 128, 4>), grid, dim3(512), 0, s, a);
     } else {
         dim3 grid((unsigned)n, (unsigned)o.batch);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 2>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<0, 128, 2>), grid, dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 2>), grid, dim3(256), 0, s, a);
+            GP_LAUNCH((gemm_nt_kernel<1, 128, 2>), grid, dim3(256), 0, s, a);
     }
 }
 

@@ -11,6 +11,21 @@
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// ---- launch / stream-operation checks ---------------------------------------------------------------------------------
+// A refused kernel launch (resources, bad configuration) or a failed event record / stream wait reports through the HIP
+// call's return value only; the launch_* helpers return void and sit many frames below the entry point.  Every launch and
+// every stream-ordering call therefore NOTES its status in a per-thread slot (the first failure wins), and the entry
+// points read that slot where they synchronise (GP_SYNC in api_internal.h): a failure anywhere in the call becomes
+// GP_ERR_HIP with the kernel / call named, never a success over unwritten results.
+void gp_note_hip(hipError_t e, const char *what, const char *file, int line);
+#define GP_NOTE(call) gp_note_hip((call), #call, __FILE__, __LINE__)
+#define GP_LAUNCH(kernel, grid, block, lds, stream, ...)                                   \
+    do {                                                                                   \
+        (void)hipGetLastError(); /* a stale status of an earlier, handled call is not this launch's */ \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                 \
+        gp_note_hip(hipGetLastError(), #kernel, __FILE__, __LINE__);                       \
+    } while (0)
+
 // ---- kernel parameters of the stationary covariance (device copy) ----------
 #define GP_MAX_D 64
 struct KernParams {
@@ -94,6 +109,7 @@ void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *
 // its inverse (row-major 128x128, lower, zero above) to invL + t*128*128.
 // info: device int, 0 = ok, else 1-based global column of the first non-positive pivot.
 void launch_potrf_tile(hipStream_t s, double *A, long lda, int t, double *invL, int *info);
+void potrf_set_debug_lds(int bytes);   // test hook: dynamic LDS added to every diagonal-tile launch (a refused launch beyond ~9 KB)
 
 // Ky lower tiles (incl. diagonal tiles in full) from X; padding rows get identity.
 void launch_kbuild(hipStream_t s, double *A, long lda, const double *X, long N, long Npad,

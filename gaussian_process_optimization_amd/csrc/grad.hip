@@ -50,7 +50,7 @@ __global__ void set_identity_kernel(double *T, long ld, long n) {
 }
 void launch_set_identity(hipStream_t s, double *T, long ld, long n) {
     dim3 grid((unsigned)((n / 2 + 255) / 256), (unsigned)n);
-    hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, T, ld, n);
+    GP_LAUNCH(set_identity_kernel, grid, dim3(256), 0, s, T, ld, n);
 }
 
 // upper <- lower, 32x32 LDS transpose tiles
@@ -90,11 +90,11 @@ __global__ void symmetrize_scale_kernel(double *A, long ld, long n, double scale
 }
 void launch_symmetrize_scale(hipStream_t s, double *A, long ld, long n, double scale) {
     const unsigned nb = (unsigned)((n + 31) / 32);
-    hipLaunchKernelGGL(symmetrize_scale_kernel, dim3(nb, nb), dim3(256), 0, s, A, ld, n, scale);
+    GP_LAUNCH(symmetrize_scale_kernel, dim3(nb, nb), dim3(256), 0, s, A, ld, n, scale);
 }
 void launch_symmetrize(hipStream_t s, double *A, long ld, long n) {
     const unsigned nb = (unsigned)((n + 31) / 32);
-    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, s, A, ld, n);
+    GP_LAUNCH(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, s, A, ld, n);
 }
 
 // ---- LML hyper-gradients: one pass over the lower tiles ------------------------------------------
@@ -212,9 +212,9 @@ void launch_lml_grad(hipStream_t s, const double *X, long N, long Npad, const Ke
     const int nt = (int)(Npad / GP_TILE);
     const long ntile = (long)nt * (nt + 1) / 2;
     const size_t shm = ((size_t)2 * kp.D * GP_TILE + (size_t)2 * P * GP_TILE) * sizeof(double);
-    hipLaunchKernelGGL(lml_grad_tile_kernel, dim3((unsigned)ntile), dim3(256), shm, s, X, N, kp, ard, d0, alpha, Npad,
+    GP_LAUNCH(lml_grad_tile_kernel, dim3((unsigned)ntile), dim3(256), shm, s, X, N, kp, ard, d0, alpha, Npad,
                        P, Wi, ldw, partial);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(NACC), dim3(1024), 0, s, partial, ntile, NACC, out);
+    GP_LAUNCH(sum_partials_kernel, dim3(NACC), dim3(1024), 0, s, partial, ntile, NACC, out);
 }
 
 // ---- predictive gradients (gp.py:407-454) ----------------------------------------------------------
@@ -280,7 +280,7 @@ void launch_predict_grad(hipStream_t s, const double *Xs, long M, const double *
                          const double *alpha, long lda_, int P, const double *beta, long ldb, double *dmdx,
                          double *dvdx) {
     for (int d0 = 0; d0 < kp.D; d0 += GCH)
-        hipLaunchKernelGGL(predict_grad_kernel, dim3((unsigned)M), dim3(256), 0, s, Xs, X, N, kp, alpha, lda_, P, beta,
+        GP_LAUNCH(predict_grad_kernel, dim3((unsigned)M), dim3(256), 0, s, Xs, X, N, kp, alpha, lda_, P, beta,
                            ldb, d0, dmdx, dvdx);
 }
 
@@ -325,7 +325,7 @@ __global__ void acq_grad_kernel(int type, double par, double fmin, double y_mean
 void launch_acq_grad(hipStream_t s, int type, double par, double fmin, double y_mean, double y_std, const double *mean,
                      const double *var, const double *dmdx, const double *dvdx, long M, int D, double *out,
                      double *dout) {
-    hipLaunchKernelGGL(acq_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, type, par, fmin, y_mean,
+    GP_LAUNCH(acq_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, type, par, fmin, y_mean,
                        y_std, mean, var, dmdx, dvdx, M, D, out, dout);
 }
 
@@ -335,7 +335,7 @@ __global__ void add_diag2_kernel(double *A, long lda, long n, double v) {
     if (i < n) A[i * lda + i] += v;
 }
 void launch_add_diag(hipStream_t s, double *A, long lda, long N, double v) {
-    hipLaunchKernelGGL(add_diag2_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, A, lda, N, v);
+    GP_LAUNCH(add_diag2_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, A, lda, N, v);
 }
 // tr = sum_i A[i][i]
 __global__ __launch_bounds__(1024) void trace_kernel(const double *A, long lda, long N, double *out) {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(1024) void trace_kernel(const double *A, long lda, 
     }
 }
 void launch_trace(hipStream_t s, const double *A, long lda, long N, double *out) {
-    hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1024), 0, s, A, lda, N, out);
+    GP_LAUNCH(trace_kernel, dim3(1), dim3(1024), 0, s, A, lda, N, out);
 }
 
 __global__ void set_identity_blocks_kernel(double *T, long n) {
@@ -367,7 +367,7 @@ __global__ void set_identity_blocks_kernel(double *T, long n) {
 }
 void launch_set_identity_blocks(hipStream_t s, double *T, long n, int nb) {
     dim3 grid((unsigned)((n / 2 + 255) / 256), (unsigned)(n * nb));
-    hipLaunchKernelGGL(set_identity_blocks_kernel, grid, dim3(256), 0, s, T, n);
+    GP_LAUNCH(set_identity_blocks_kernel, grid, dim3(256), 0, s, T, n);
 }
 __global__ void transpose_blocks_kernel(double *dst, const double *src, long n) {
     __shared__ double t[32][33];
@@ -381,7 +381,7 @@ __global__ void transpose_blocks_kernel(double *dst, const double *src, long n) 
 }
 void launch_transpose_blocks(hipStream_t s, double *dst, const double *src, long n, int nb) {
     dim3 grid((unsigned)(n / 32), (unsigned)(n / 32), (unsigned)nb);
-    hipLaunchKernelGGL(transpose_blocks_kernel, grid, dim3(256), 0, s, dst, src, n);
+    GP_LAUNCH(transpose_blocks_kernel, grid, dim3(256), 0, s, dst, src, n);
 }
 
 // ---- local-penalisation epilogue (GPyOpt/GPyOpt/acquisitions/LP.py:40-110) -----------------------------
@@ -429,7 +429,7 @@ __global__ void lp_kernel(const double *negacq, const double *Xs, long M, int D,
 }
 void launch_lp(hipStream_t s, const double *negacq, const double *Xs, long M, int D, const double *Xb, int nb,
                const double *r0, const double *s0, int transform, double *out) {
-    hipLaunchKernelGGL(lp_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, negacq, Xs, M, D, Xb, nb, r0, s0,
+    GP_LAUNCH(lp_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, negacq, Xs, M, D, Xb, nb, r0, s0,
                        transform, out);
 }
 // value and gradient of the penalised acquisition (LP.py:112-140).  in: negacq[M] = -acq(x), dneg[M, D] = -d acq / dx (the
@@ -468,7 +468,7 @@ __global__ void lp_grad_kernel(double *negacq, double *dneg, const double *Xs, l
 }
 void launch_lp_grad(hipStream_t s, double *negacq, double *dneg, const double *Xs, long M, int D, const double *Xb, int nb,
                     const double *r0, const double *s0, int transform) {
-    hipLaunchKernelGGL(lp_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, negacq, dneg, Xs, M, D, Xb, nb, r0,
+    GP_LAUNCH(lp_grad_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, negacq, dneg, Xs, M, D, Xb, nb, r0,
                        s0, transform);
 }
 __global__ void mask_kernel(double *v, const long long *idx, int n, double fill) {
@@ -476,7 +476,7 @@ __global__ void mask_kernel(double *v, const long long *idx, int n, double fill)
     if (i < n) v[idx[i]] = fill;
 }
 void launch_mask(hipStream_t s, double *v, const long long *idx, int n, double fill) {
-    if (n > 0) hipLaunchKernelGGL(mask_kernel, dim3(1), dim3(256), 0, s, v, idx, n, fill);
+    if (n > 0) GP_LAUNCH(mask_kernel, dim3(1), dim3(256), 0, s, v, idx, n, fill);
 }
 
 __global__ __launch_bounds__(256) void dldk_kernel(double *out, long ldo, const double *alpha, long lda_, int P,
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void dldk_kernel(double *out, long ldo, const 
 }
 void launch_dldk(hipStream_t s, double *out, long ldo, const double *alpha, long lda_, int P, const double *Wi,
                  long ldw, long N) {
-    hipLaunchKernelGGL(dldk_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, s, out, ldo, alpha,
+    GP_LAUNCH(dldk_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, s, out, ldo, alpha,
                        lda_, P, Wi, ldw, N);
 }
 
@@ -501,5 +501,5 @@ __global__ __launch_bounds__(256) void zero_upper_diag_kernel(double *A, long ld
     }
 }
 void launch_zero_upper_diag(hipStream_t s, double *A, long lda, int nt) {
-    hipLaunchKernelGGL(zero_upper_diag_kernel, dim3((unsigned)nt), dim3(256), 0, s, A, lda);
+    GP_LAUNCH(zero_upper_diag_kernel, dim3((unsigned)nt), dim3(256), 0, s, A, lda);
 }

@@ -139,11 +139,11 @@ void launch_kbuild(hipStream_t s, double *A, long lda, const double *X, long N, 
     const int DU = kp.gower ? 0 : (kp.D <= 8 ? 8 : (kp.D <= 16 ? 16 : 0));
     const size_t shm = (size_t)2 * (DU ? DU : kp.D) * GP_TILE * sizeof(double);
     if (DU == 8)
-        hipLaunchKernelGGL(kbuild_kernel<8>, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp, diag_add, full, nt);
+        GP_LAUNCH(kbuild_kernel<8>, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp, diag_add, full, nt);
     else if (DU == 16)
-        hipLaunchKernelGGL(kbuild_kernel<16>, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp, diag_add, full, nt);
+        GP_LAUNCH(kbuild_kernel<16>, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp, diag_add, full, nt);
     else
-        hipLaunchKernelGGL(kbuild_kernel<0>, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp, diag_add, full, nt);
+        GP_LAUNCH(kbuild_kernel<0>, dim3((unsigned)nblk), dim3(256), shm, s, A, lda, X, N, Npad, kp, diag_add, full, nt);
 }
 
 __global__ void set_rhs_kernel(double *A, long lda, const double *Y, long N, long Npad, int P) {
@@ -155,7 +155,7 @@ __global__ void set_rhs_kernel(double *A, long lda, const double *Y, long N, lon
 
 void launch_set_rhs(hipStream_t s, double *A, long lda, const double *Y, long N, long Npad, int P) {
     dim3 grid((unsigned)((Npad + 255) / 256), GP_MAX_RHS);
-    hipLaunchKernelGGL(set_rhs_kernel, grid, dim3(256), 0, s, A, lda, Y, N, Npad, P);
+    GP_LAUNCH(set_rhs_kernel, grid, dim3(256), 0, s, A, lda, Y, N, Npad, P);
 }
 
 // T[c][i] = k(xs_c, x_i); tiles (tc over candidates, ti over training points)
@@ -233,9 +233,9 @@ void launch_cross_k(hipStream_t s, double *T, long ldt, const double *Xs, long M
     const size_t shm = (size_t)2 * (DU ? DU : kp.D) * GP_TILE * sizeof(double);
     const dim3 grid((unsigned)((long)ntc * nti));
     if (DU == 8)
-        hipLaunchKernelGGL(cross_k_kernel<8>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
+        GP_LAUNCH(cross_k_kernel<8>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
     else if (DU == 16)
-        hipLaunchKernelGGL(cross_k_kernel<16>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
+        GP_LAUNCH(cross_k_kernel<16>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
     else
-        hipLaunchKernelGGL(cross_k_kernel<0>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
+        GP_LAUNCH(cross_k_kernel<0>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
 }

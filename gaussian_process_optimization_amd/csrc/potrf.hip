@@ -506,6 +506,11 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, in
     potrf_tile_body(A, lda, t, invL, info, T, Dinv, zrow);
 }
 
+// Test hook (option "debug_potrf_lds"): extra dynamic LDS requested with every diagonal-tile launch.  Beyond what the CU has
+// left beside the kernel's 151 KB of static LDS the launch is REFUSED -- which is what the launch checks are there to catch.
+static int g_debug_lds = 0;
+void potrf_set_debug_lds(int bytes) { g_debug_lds = bytes; }
+
 void launch_potrf_tile(hipStream_t s, double *A, long lda, int t, double *invL, int *info) {
-    hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), 0, s, A, lda, t, invL, info);
+    GP_LAUNCH(potrf_tile_kernel, dim3(1), dim3(512), (size_t)g_debug_lds, s, A, lda, t, invL, info);
 }

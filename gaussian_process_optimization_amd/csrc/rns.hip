@@ -112,7 +112,7 @@ void launch_rns_convert(hipStream_t s, const double *src, long ld, long rows, lo
                         long plane_stride, long ldd, double scale, int *flag) {
     const long cols4 = cols / 4;
     dim3 grid((unsigned)((cols4 + 255) / 256), (unsigned)rows);
-    hipLaunchKernelGGL(rns_convert_kernel, grid, dim3(256), 0, s, src, ld, rows, cols4, dst, plane_stride, ldd, scale, flag);
+    GP_LAUNCH(rns_convert_kernel, grid, dim3(256), 0, s, src, ld, rows, cols4, dst, plane_stride, ldd, scale, flag);
 }
 
 // Accumulator residues are stored as UNSIGNED bytes, any representative in [0, p + 2] (<= 255): the accumulator is never
@@ -362,7 +362,7 @@ void launch_rns_gemm256(hipStream_t s, const signed char *A, long lda, long a_pl
     a.sr = (mt + 7) / 8;
     a.sc = (c1 - c0 + 3) / 4;
     const long nwg = ((long)RNS_T * a.sr * a.sc + 7) / 8 * 8 * 32;   // whole rounds of eight super-tiles (one per XCD)
-    hipLaunchKernelGGL(rns_gemm256_kernel, dim3((unsigned)nwg), dim3(512), 0, s, a);
+    GP_LAUNCH(rns_gemm256_kernel, dim3((unsigned)nwg), dim3(512), 0, s, a);
 }
 
 // reconstruction from the 64 KB blocks: one workgroup (512 threads, the GEMM's thread layout) per (256-row tile,
@@ -437,6 +437,6 @@ void launch_rns_reconstruct256(hipStream_t s, const signed char *R, int mt_all, 
     for (int l = 0; l < RNS_T; ++l) Pl *= (long double)h_moduli[l];
     const double P_scaled = (double)(Pl * 0x1p-104L);
     const int tc0 = c0_128 / 2, tc1 = (c1_128 + 1) / 2;
-    hipLaunchKernelGGL(rns_reconstruct256_kernel, dim3((unsigned)(8 * mt * (tc1 - tc0))), dim3(512), 0, s, R, mt_all, nt_all, tc0,
+    GP_LAUNCH(rns_reconstruct256_kernel, dim3((unsigned)(8 * mt * (tc1 - tc0))), dim3(512), 0, s, R, mt_all, nt_all, tc0,
                        tc1 - tc0, c0_128, c1_128, rows, T, ldt, P_scaled * scale_2e, tri);
 }

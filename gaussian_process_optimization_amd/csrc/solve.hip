@@ -38,7 +38,7 @@ __global__ __launch_bounds__(1024) void logdet_kernel(const double *A, long lda,
     if (threadIdx.x == 0) out[0] = 2.0 * s;
 }
 void launch_logdet(hipStream_t s, const double *A, long lda, long N, double *out) {
-    hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, s, A, lda, N, out);
+    GP_LAUNCH(logdet_kernel, dim3(1), dim3(1024), 0, s, A, lda, N, out);
 }
 
 // ---- out[p] = z_p . z_p  (= Y^T Ky^-1 Y, the data-fit term of exact_gaussian_inference.py:62) ----
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(1024) void rhs_sumsq_kernel(const double *A, long l
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 void launch_rhs_sumsq(hipStream_t s, const double *A, long lda, long N, long Npad, int P, double *out) {
-    hipLaunchKernelGGL(rhs_sumsq_kernel, dim3(P), dim3(1024), 0, s, A, lda, N, Npad, out);
+    GP_LAUNCH(rhs_sumsq_kernel, dim3(P), dim3(1024), 0, s, A, lda, N, Npad, out);
 }
 
 // ---- alpha = L^-T z  (second half of dpotrs, exact_gaussian_inference.py:60) -------------------
@@ -139,7 +139,7 @@ __global__ void zero_kernel(double *p, long n) {
 void launch_trsv_backward(hipStream_t s, const double *L, long lda, const double *invP, int W, long Npad,
                           const double *Z, long ldz, int P, double *Aout, double *w) {
     const long nw = (long)P * Npad;
-    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w, nw);
+    GP_LAUNCH(zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w, nw);
     const int nt = (int)(Npad / GP_TILE);
     const long PB = (long)W * GP_TILE;
     const int nJ = (nt + W - 1) / W;
@@ -147,10 +147,10 @@ void launch_trsv_backward(hipStream_t s, const double *L, long lda, const double
         const int J0 = J * W, J1 = std::min(J0 + W, nt);
         const int Kp = (J1 - J0) * GP_TILE;
         const long off = (long)J0 * GP_TILE;
-        hipLaunchKernelGGL(panel_solve_kernel, dim3(J1 - J0), dim3(PT), Kp * sizeof(double), s, invP + (long)J * PB * PB,
+        GP_LAUNCH(panel_solve_kernel, dim3(J1 - J0), dim3(PT), Kp * sizeof(double), s, invP + (long)J * PB * PB,
                            PB, Kp, Z, ldz, w, Npad, P, off, Aout);
         if (J0 > 0)
-            hipLaunchKernelGGL(panel_update_kernel, dim3(J0), dim3(PT), Kp * sizeof(double), s, L, lda, Kp, off, Aout,
+            GP_LAUNCH(panel_update_kernel, dim3(J0), dim3(PT), Kp * sizeof(double), s, L, lda, Kp, off, Aout,
                                ldz, P, w, Npad);
     }
 }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void predict_reduce_kernel(const double *T, lo
 void launch_predict_reduce(hipStream_t s, const double *T, long ldt, long M, long N, const double *Z, long ldz, int P,
                            double kss, double noise_add, double *mean, double *var) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)M), dim3(256), 0, s, T, ldt, N, Z, ldz, P, kss, noise_add,
+    GP_LAUNCH(predict_reduce_kernel, dim3((unsigned)M), dim3(256), 0, s, T, ldt, N, Z, ldz, P, kss, noise_add,
                        mean, var);
 }
 
@@ -275,8 +275,8 @@ __global__ void train_mean_sum_kernel(const double *part, long N, double *mu) {
 void launch_train_mean(hipStream_t s, const double *X, long N, const KernParams &kp, const double *alpha, double *mu) {
     const size_t shm = ((size_t)2 * kp.D * GP_TILE + GP_TILE) * sizeof(double);
     dim3 grid((unsigned)((N + GP_TILE - 1) / GP_TILE), TM_SPLIT);
-    hipLaunchKernelGGL(train_mean_kernel, grid, dim3(256), shm, s, X, N, kp, alpha, mu + N);
-    hipLaunchKernelGGL(train_mean_sum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, mu + N, N, mu);
+    GP_LAUNCH(train_mean_kernel, grid, dim3(256), shm, s, X, N, kp, alpha, mu + N);
+    GP_LAUNCH(train_mean_sum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, mu + N, N, mu);
 }
 
 // Posterior mean at the training inputs from the normal equations instead of an N^2 pass:
@@ -288,7 +288,7 @@ __global__ void train_mean_identity_kernel(const double *Y, const double *alpha,
     if (i < N) mu[i] = fma(-d, alpha[i], Y[i]);
 }
 void launch_train_mean_identity(hipStream_t s, const double *Y, const double *alpha, double d, long N, double *mu) {
-    hipLaunchKernelGGL(train_mean_identity_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Y, alpha, d, N, mu);
+    GP_LAUNCH(train_mean_identity_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Y, alpha, d, N, mu);
 }
 
 // ---- min / arg-best (NumPy tie rule: lowest index) -------------------------------------------
@@ -327,9 +327,9 @@ void launch_argbest(hipStream_t s, const double *v, long n, int sense, double *b
     int nb = (int)((n + 255) / 256);
     if (nb > 256) nb = 256;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(argbest_kernel, dim3(nb), dim3(256), 0, s, v, n, sense, scratch_val, scratch_idx,
+    GP_LAUNCH(argbest_kernel, dim3(nb), dim3(256), 0, s, v, n, sense, scratch_val, scratch_idx,
                        (const long long *)nullptr);
-    hipLaunchKernelGGL(argbest_kernel, dim3(1), dim3(256), 0, s, scratch_val, (long)nb, sense, best_val, best_idx,
+    GP_LAUNCH(argbest_kernel, dim3(1), dim3(256), 0, s, scratch_val, (long)nb, sense, best_val, best_idx,
                        (const long long *)scratch_idx);
 }
 void launch_min(hipStream_t s, const double *v, long n, double *out) {
@@ -364,6 +364,6 @@ __global__ void acq_kernel(int type, double par, double fmin, double y_mean, dou
 void launch_acq(hipStream_t s, int type, double par, double fmin, double y_mean, double y_std, const double *mean,
                 const double *var, long M, double *out) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(acq_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, type, par, fmin, y_mean, y_std,
+    GP_LAUNCH(acq_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, type, par, fmin, y_mean, y_std,
                        mean, var, M, out);
 }

@@ -137,3 +137,32 @@ def test_local_penalization_host_route_equals_device_route():
         np.testing.assert_allclose(fd, fh, rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(dd, dh, rtol=1e-7, atol=1e-9 * np.max(np.abs(dh)))
     gm.model.close()
+
+
+def test_refused_launch_fails_the_call_instead_of_returning_a_stale_result():
+    """Every kernel launch and every stream-ordering call is checked (GP_LAUNCH / GP_NOTE / GP_SYNC): with the diagonal-tile
+    kernel asked for more LDS than a CU has, its launch is refused -- gp_fit used to return success with info == 0 over an
+    unfactored matrix (jitchol would have raised, linalg.py:56-81); now every entry point that factors reports a HIP error
+    naming the kernel, the side streams are drained, and the same context works again once the hook is off."""
+    X, Y, Xs = O.synthetic_problem(1700, 3, 300, seed=2)     # 14 tiles: look-ahead scheduler for the one-call entry points
+    h = _lib.Handle(0)
+    h.set_data(X, Y)
+    h.set_params(0, 0, 1.0, [0.4], 1e-2)
+    h.set_candidates(Xs)
+    good = h.fit()
+    mu, var = h.predict(True)
+    h.set_option("debug_potrf_lds", 200 * 1024)
+    try:
+        for call in (h.fit, lambda: h.fit_predict(True), lambda: h.fit_grad(1)):
+            with pytest.raises(RuntimeError) as ei:
+                call()
+            assert "potrf_tile_kernel" in str(ei.value)
+        with pytest.raises(RuntimeError):
+            h.predict(True)                                  # nothing fitted any more: a state error, not stale numbers
+    finally:
+        h.set_option("debug_potrf_lds", 0)
+    again = h.fit()
+    assert again == good
+    mu2, var2 = h.predict(True)
+    assert np.array_equal(mu, mu2) and np.array_equal(var, var2)
+    h.close()

@@ -4,6 +4,11 @@
 #include <cstdio>
 #include <vector>
 #include "../../gaussian_process_optimization_amd/csrc/gphip_internal.h"
+
+// the library's launch-status slot (api_core.hip) is not linked into this stand-alone tool: report to stderr instead
+void gp_note_hip(hipError_t e, const char *what, const char *file, int line) {
+    if (e != hipSuccess) fprintf(stderr, "%s -> %s (%s:%d)\n", what, hipGetErrorString(e), file, line);
+}
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 int main() {
     const long N = 16384, lda = N;

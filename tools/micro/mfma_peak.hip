@@ -5,6 +5,11 @@
 #include <vector>
 #include "../../gaussian_process_optimization_amd/csrc/gphip_internal.h"
 
+// the library's launch-status slot (api_core.hip) is not linked into this stand-alone tool: report to stderr instead
+void gp_note_hip(hipError_t e, const char *what, const char *file, int line) {
+    if (e != hipSuccess) fprintf(stderr, "%s -> %s (%s:%d)\n", what, hipGetErrorString(e), file, line);
+}
+
 template <int NACC>
 __global__ __launch_bounds__(256) void mfma_loop(double *out, int iters) {
     double4_t acc[NACC];

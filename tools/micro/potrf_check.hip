@@ -7,6 +7,11 @@
 #include <cmath>
 #include <cstdio>
 #include <vector>
+
+// the library's launch-status slot (api_core.hip) is not linked into this stand-alone tool: report to stderr instead
+void gp_note_hip(hipError_t e, const char *what, const char *file, int line) {
+    if (e != hipSuccess) fprintf(stderr, "%s -> %s (%s:%d)\n", what, hipGetErrorString(e), file, line);
+}
 #ifndef POTRF_NSTAMPS
 #define POTRF_NSTAMPS 32
 #endif

@@ -218,7 +218,7 @@ struct PredPipe {
 struct RnsGeom {
     int e = 0;
     double scale = 1.0, back = 1.0;
-    long Lrows = 0, Lplane = 0, Lpitch = 0;   // row pitch of the residue planes of L in bytes: NOT a power of two
+    long Lrows = 0, Lplane = 0, Lpitch = 0;   // row pitch of the residue planes of L in bytes (= Npad, api_rns.hip)
     int nt256 = 0;
 };
 

@@ -317,6 +317,7 @@ extern "C" int gp_posterior_samples(gp_t *g, int include_noise, const double *Z,
                             hipMemcpyHostToDevice, g->s));
     // jitchol scales its ladder by the mean of the diagonal of the matrix it factors (linalg.py:62-66: diagA.mean() * 1e-6):
     // here the POSTERIOR covariance, whose diagonal near training points is orders of magnitude below the prior variance
+    double diag_stat[2] = {0.0, 0.0};   // trace and smallest entry of the diagonal of the matrix to factor
     double diag_mean = 0.0;
     double jitter = 0.0;
     int tries = 0, info = 0;
@@ -326,7 +327,7 @@ extern "C" int gp_posterior_samples(gp_t *g, int include_noise, const double *Z,
         if (include_noise) launch_add_diag(g->s, C, Mpad, M, g->noise);
         if (tries == 0) {
             launch_trace(g->s, C, Mpad, M, g->dScal + 420);
-            HIPCHK(hipMemcpyAsync(&diag_mean, g->dScal + 420, sizeof(double), hipMemcpyDeviceToHost, g->s));
+            HIPCHK(hipMemcpyAsync(diag_stat, g->dScal + 420, 2 * sizeof(double), hipMemcpyDeviceToHost, g->s));
         }
         if (jitter != 0.0) launch_add_diag(g->s, C, Mpad, M, jitter);
         HIPCHK(hipMemsetAsync(g->dInfo, 0, sizeof(int) * 4, g->s));
@@ -340,8 +341,10 @@ extern "C" int gp_posterior_samples(gp_t *g, int include_noise, const double *Z,
         }
         if (info == 0) break;
         // jitchol: mean(diag) * 1e-6 * 10^k (linalg.py:62-75)
-        if (tries == 0) diag_mean /= (double)M;
-        if (!(diag_mean > 0.0)) return fail(GP_ERR_NOT_PD_DIAG, "not pd: non-positive diagonal elements");
+        if (tries == 0) diag_mean = diag_stat[0] / (double)M;
+        // np.any(diagA <= 0.) raises before any jitter is tried (linalg.py:61-62): ANY entry, not the mean -- a posterior
+        // variance that came out slightly negative at a training point is such an entry
+        if (diag_stat[1] <= 0.0 || !(diag_mean > 0.0)) return fail(GP_ERR_NOT_PD_DIAG, "not pd: non-positive diagonal elements");
         jitter = tries == 0 ? diag_mean * 1e-6 : jitter * 10.0;
         if (++tries > maxtries || !std::isfinite(jitter)) {
             g_err = "not positive definite, even with jitter.";

@@ -165,7 +165,7 @@ void launch_acq_grad(hipStream_t s, int type, double par, double fmin, double y_
                      const double *var, const double *dmdx, const double *dvdx, long M, int D, double *out,
                      double *dout);
 void launch_add_diag(hipStream_t s, double *A, long lda, long N, double v);
-void launch_trace(hipStream_t s, const double *A, long lda, long N, double *out);
+void launch_trace(hipStream_t s, const double *A, long lda, long N, double *out);   // out[0] = trace, out[1] = smallest diagonal entry
 
 // nb blocks of n x n (row-major, leading dimension n, stacked): identity / transpose (dst_b = src_b^T)
 void launch_set_identity_blocks(hipStream_t s, double *T, long n, int nb);

@@ -337,18 +337,30 @@ __global__ void add_diag2_kernel(double *A, long lda, long n, double v) {
 void launch_add_diag(hipStream_t s, double *A, long lda, long N, double v) {
     GP_LAUNCH(add_diag2_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, A, lda, N, v);
 }
-// tr = sum_i A[i][i]
+// out[0] = sum_i A[i][i], out[1] = min_i A[i][i]  (jitchol looks at both: linalg.py:61-66)
 __global__ __launch_bounds__(1024) void trace_kernel(const double *A, long lda, long N, double *out) {
-    __shared__ double sh[16];
-    double s = 0.0;
-    for (long i = threadIdx.x; i < N; i += 1024) s += A[i * lda + i];
+    __shared__ double sh[16], shm[16];
+    double s = 0.0, mn = INFINITY;
+    for (long i = threadIdx.x; i < N; i += 1024) {
+        const double d = A[i * lda + i];
+        s += d;
+        mn = fmin(mn, d);
+    }
     s = wave_sum_g(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    for (int o = 32; o > 0; o >>= 1) mn = fmin(mn, __shfl_down(mn, o));
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = s;
+        shm[threadIdx.x >> 6] = mn;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double r = 0.0;
-        for (int i = 0; i < 16; ++i) r += sh[i];
+        double r = 0.0, m = INFINITY;
+        for (int i = 0; i < 16; ++i) {
+            r += sh[i];
+            m = fmin(m, shm[i]);
+        }
         out[0] = r;
+        out[1] = m;
     }
 }
 void launch_trace(hipStream_t s, const double *A, long lda, long N, double *out) {

@@ -34,7 +34,7 @@
 #include "gphip_internal.h"
 
 #ifdef POTRF_STAMPS
-// diagnostic build only (tools/micro/potrf_bench.hip): cycle stamps of wave 0 into a buffer of their own
+// diagnostic build only (tools/micro/potrf_check.hip): cycle stamps of wave 0 into a buffer of their own
 __device__ unsigned long long g_potrf_stamps[64];
 #define STAMP(i)                                                                                  \
     do {                                                                                          \
@@ -106,8 +106,10 @@ __device__ __forceinline__ int eliminate_panel(double *T, const double *zero, in
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const double akk = readlane_d(a[k], k);
-        if (lane == k) piv = akk;
         const double rk = fast_rcp(akk);
+        // a positive pivot too small to invert (subnormal: v_rcp_f64 overflows and the Newton steps give NaN) counts as a failed
+        // pivot, like a non-positive one: the tile then goes through the jitter ladder instead of coming back as NaN with info 0
+        if (lane == k) piv = (fabs(rk) < __builtin_inf()) ? akk : -1.0;
         const double m = a[k] * rk;                 // a_ik / a_kk
         // a_jk (row j of the diagonal block) through v_readlane, four at a time: the scalar results of one group are
         // consumed by the FMAs while the next group's reads issue (a VALU read of a just-written SGPR costs wait states)

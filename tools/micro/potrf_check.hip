@@ -1,6 +1,6 @@
 // Stand-alone check + cycle stamps of the diagonal-tile kernel (test tooling; never shipped).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DPOTRF_SRC='"<path to potrf.hip>"' potrf_check.hip -o potrf_check
-// Factors several 128x128 tiles (well / ill conditioned, identity padding, a non-positive pivot), compares L and L^-1 with a
+// Factors several 128x128 tiles (well / ill conditioned, identity padding, a non-positive pivot, a subnormal pivot), compares L and L^-1 with a
 // long-double host Cholesky / substitution, and prints the kernel's own cycle stamps.
 #define POTRF_STAMPS 1
 #include POTRF_SRC
@@ -48,7 +48,7 @@ int main() {
     CHK(hipMalloc(&dA, (size_t)lda * lda * 8)); CHK(hipMalloc(&dI, 3 * n * n * 8)); CHK(hipMalloc(&dinfo, 16));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     int bad_total = 0;
-    for (int tc = 0; tc < 6; ++tc) {
+    for (int tc = 0; tc < 7; ++tc) {
         std::vector<double> A((size_t)n * n);
         int expect_info = 0;
         for (int i = 0; i < n; ++i)
@@ -60,12 +60,14 @@ int main() {
                     v = (a >= 0 && b >= 0) ? 3.0 * std::exp(-std::fabs((double)(a - b)) / 7.0) + (a == b ? 0.5 : 0) : (i == j ? 1.0 : 0.0); }
                 else if (tc == 3) v = (i == j ? 2.0 + 0.01 * i : 1.0 / (1.0 + std::abs(i - j)) * ((i + j) % 3 == 0 ? -0.5 : 0.4) / 8.0);
                 else if (tc == 4) v = std::exp(-0.5 * (i - j) * (i - j) / 400.0) + (i == j ? (i == 77 ? -5.0 : 0.01) : 0.0);   // pivot 78 fails
+                else if (tc == 6) v = (i == j) ? (i == 37 ? 1e-310 : 1.0) : 0.0;   // a positive SUBNORMAL pivot: its reciprocal overflows -> reported like a non-positive one (column 38)
                 else v = std::exp(-0.5 * (i - j) * (i - j) / 50.0) * (1.0 + 0.3 * std::sin(i * 0.37) * std::sin(j * 0.37)) + (i == j ? 0.05 : 0);
                 A[i * n + j] = v;
             }
         std::vector<long double> L, Iv;
         const int hinfo = host_chol(A, n, L);
         if (hinfo) expect_info = t * n + hinfo;
+        if (tc == 6) expect_info = t * n + 38;
         std::vector<double> big((size_t)lda * lda, 777.0);
         for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) big[(size_t)(t * n + i) * lda + t * n + j] = A[i * n + j];
         CHK(hipMemcpy(dA, big.data(), big.size() * 8, hipMemcpyHostToDevice));
@@ -79,7 +81,7 @@ int main() {
         std::vector<double> out((size_t)lda * lda), inv((size_t)3 * n * n);
         CHK(hipMemcpy(out.data(), dA, out.size() * 8, hipMemcpyDeviceToHost));
         CHK(hipMemcpy(inv.data(), dI, inv.size() * 8, hipMemcpyDeviceToHost));
-        if (hinfo) { printf("case %d: host info %d, device info %d (expected %d) %s\n", tc, hinfo, info, expect_info, info == expect_info ? "OK" : "MISMATCH"); bad_total += info != expect_info; continue; }
+        if (hinfo || tc == 6) { printf("case %d: host info %d, device info %d (expected %d) %s\n", tc, hinfo, info, expect_info, info == expect_info ? "OK" : "MISMATCH"); bad_total += info != expect_info; continue; }
         host_inv(L, n, Iv);
         double eL = 0, eI = 0, mL = 0, mI = 0, eOut = 0, eUp = 0;
         for (int i = 0; i < n; ++i)

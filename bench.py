@@ -17,18 +17,22 @@ hyper-parameters fixed.
     iterations/s (NOT multiplied by the rank count).  One process per GPU: either launched by torch.distributed.run
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- called plainly as `python bench.py --gpus N`
     -- this process becomes a launcher that makes NO HIP / RCCL call itself and starts N fresh rank processes
-    (launch_ranks below; never a re-exec of a process that touched the GPU).  torch is used for rendezvous / barrier /
-    max-over-ranks only (gloo), the data path is libgphip + its RCCL communicator.  The ranks compare their merged
-    winners at the end; a disagreement is exit code 3.  --workload c3|c4 overrides the automatic choice (e.g. C4 on one
-    GPU as the strong-scaling base).
+    (launch_ranks below; never a re-exec of a process that touched the GPU).  No rank imports torch: the 128-byte RCCL
+    unique id and the end-of-run records travel over a local socket between the ranks (Rendezvous below), and with the
+    RCCL communicator up the barrier and the max-over-ranks of the elapsed time are all-gathers inside libgphip
+    (gp_comm_allgather_best); the JSON line records which librccl the process mapped and the version it reports.  The ranks
+    compare their merged winners at the end; a disagreement is exit code 3.  --workload c3|c4 overrides the automatic
+    choice (e.g. C4 on one GPU as the strong-scaling base).
 """
 import argparse
 import hashlib
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -59,46 +63,154 @@ def shard_bounds(M, rank, nranks):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def launch_ranks(n, argv, child_cmd=None, poll_s=0.2, grace_s=20.0):
+def launch_ranks(n, argv, child_cmd=None, poll_s=0.2, grace_s=20.0, timeout_s=None):
     """`python bench.py --gpus N` without a launcher around it: start N rank processes of this script and wait.
 
     The parent touches neither HIP nor RCCL nor torch (nothing GPU-related is imported before this point), so the
     children are fresh processes, not re-execs of a process that initialised the GPU.  Each child gets RANK, LOCAL_RANK,
     WORLD_SIZE, MASTER_ADDR=127.0.0.1 and a free MASTER_PORT -- exactly what torch.distributed.run would hand it, so
-    the rank code below is the same either way.  Rank 0 inherits stdout (its ONE JSON line is the job's output), every
-    rank inherits stderr.  When a rank exits non-zero the others get `grace_s` seconds (they may be about to fail the
-    same way), then are terminated by PID; the launcher returns the first non-zero exit code."""
+    the rank code below is the same either way.  Rank 0 inherits stdout (its ONE JSON line is the job's output); the other
+    ranks' stdout goes to stderr, like every rank's stderr.  When a rank exits non-zero the others get `grace_s` seconds
+    (they may be about to fail the same way), then are terminated by PID; the launcher returns the first non-zero exit
+    code.  `timeout_s` (--launch-timeout, GPHIP_BENCH_TIMEOUT) bounds the whole job: a rank stuck in a collective or behind
+    a GPU queue that stopped draining ends the job with code 124 instead of polling for ever.  SIGTERM / SIGINT to the
+    launcher are passed on to the ranks (a supervisor that signals only this PID does not leave them holding the GPUs)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
-    s.close()
+    s.close()   # (the ranks rendezvous over a socket file keyed by this number and the launcher's PID, not over the port)
     cmd = list(child_cmd) if child_cmd is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GPHIP_BENCH_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this host driver
-        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
-    rc, t_fail = 0, None
-    while any(p.poll() is None for p in procs):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
+
+    def stop_all(sig_first=signal.SIGTERM):
         for p in procs:
-            if p.poll() not in (None, 0) and rc == 0:
-                rc, t_fail = p.returncode, time.monotonic()
-        if t_fail is not None and time.monotonic() - t_fail > grace_s:
+            if p.poll() is None:
+                p.send_signal(sig_first)
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    caught = []
+    previous = {}
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        try:
+            previous[sg] = signal.signal(sg, lambda num, frame: caught.append(num))
+        except ValueError:   # not the main thread (a test harness): no handlers, the rest is unchanged
+            pass
+    rc, t_fail, t0 = 0, None, time.monotonic()
+    try:
+        while any(p.poll() is None for p in procs):
+            if caught:
+                stop_all(caught[0])
+                return 128 + int(caught[0])
             for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
-                try:
-                    p.wait(10)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(poll_s)
+                if p.poll() not in (None, 0) and rc == 0:
+                    rc, t_fail = p.returncode, time.monotonic()
+            if t_fail is not None and time.monotonic() - t_fail > grace_s:
+                stop_all()
+                break
+            if timeout_s is not None and time.monotonic() - t0 > timeout_s:
+                sys.stderr.write("bench launcher: the job exceeded %.0f s, stopping the ranks\n" % timeout_s)
+                stop_all()
+                return 124
+            time.sleep(poll_s)
+    finally:
+        for sg, h in previous.items():
+            signal.signal(sg, h)
     for p in procs:
         if p.returncode not in (None, 0) and rc == 0:
             rc = p.returncode
     return rc if rc >= 0 else 128 - rc   # a signal's negative code as the shell reports it
+
+
+class Rendezvous(object):
+    """The ranks' control channel on ONE node, without torch: rank 0 listens on a socket file in the temp directory, named by
+    MASTER_PORT and the PID of the process that started the ranks (bench.py's launcher or torch.distributed.run: the same
+    parent for every rank), the others connect to it.  It carries small Python objects only -- the 128-byte RCCL unique id,
+    flags, the end-of-run records, and the (value, row) pairs when no RCCL communicator can be built; the data path's
+    collective is RCCL inside libgphip.  (MASTER_PORT itself is not bound: under torch.distributed.run the agent's own store
+    listens there.)"""
+
+    def __init__(self, rank, world, timeout_s=120.0):
+        from multiprocessing.connection import Client, Listener
+        self.rank, self.world = rank, world
+        key = ("gphip-bench-%s" % os.environ.get("MASTER_PORT", "0")).encode()
+        path = os.path.join(tempfile.gettempdir(), "gphip_bench_%s_%d.sock" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        self.path = path
+        self.peers = []
+        if rank == 0:
+            if os.path.exists(path):
+                os.unlink(path)          # left behind by a job of the same parent that died
+            self.listener = Listener(path, family="AF_UNIX", authkey=key)
+            self.listener._listener._socket.settimeout(timeout_s)
+            by_rank = {}
+            for _ in range(world - 1):
+                c = self.listener.accept()
+                by_rank[c.recv()] = c
+            self.peers = [by_rank[r] for r in range(1, world)]
+        else:
+            t_end = time.monotonic() + timeout_s
+            while True:
+                try:
+                    self.conn = Client(path, family="AF_UNIX", authkey=key)
+                    break
+                except (FileNotFoundError, ConnectionRefusedError):
+                    if time.monotonic() > t_end:
+                        raise RuntimeError("rank %d: rank 0 never opened %s" % (rank, path))
+                    time.sleep(0.05)
+            self.conn.send(rank)
+
+    def gather(self, obj):
+        """Rank 0 gets [obj of rank 0, obj of rank 1, ...], the others None."""
+        if self.rank == 0:
+            return [obj] + [c.recv() for c in self.peers]
+        self.conn.send(obj)
+        return None
+
+    def bcast(self, obj):
+        """Rank 0's obj on every rank."""
+        if self.rank == 0:
+            for c in self.peers:
+                c.send(obj)
+            return obj
+        return self.conn.recv()
+
+    def allgather(self, obj):
+        return self.bcast(self.gather(obj))
+
+    def barrier(self):
+        self.allgather(None)
+
+    def close(self):
+        if self.rank == 0:
+            for c in self.peers:
+                c.close()
+            self.listener.close()
+            if os.path.exists(self.path):
+                os.unlink(self.path)
+        else:
+            self.conn.close()
+
+
+def rccl_identity():
+    """Which librccl this process has mapped (the first mapping of /proc/self/maps whose file name says rccl) -- libgphip is
+    linked against /opt/rocm/lib/librccl.so.1; a python package that bundles its own copy could get in first."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                path = ln.split()[-1]
+                if "rccl" in os.path.basename(path) and path not in found:
+                    found.append(path)
+    except OSError:
+        pass
+    return found
 
 
 def cpu_baseline(N, D, M, sample_only=False):
@@ -227,13 +339,15 @@ def main():
     ap.add_argument("--separate-calls", action="store_true",
                     help="C3: time gp_fit + gp_predict as two calls instead of the one-call entry point gp_fit_predict")
     ap.add_argument("--no-emulated-line", action="store_true", help="skip the second (int8-emulated) measurement")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("GPHIP_BENCH_TIMEOUT", "0")) or None,
+                    help="--gpus N without a launcher: stop the ranks and exit 124 after this many seconds")
     ap.add_argument("--no-c4-reference", action="store_true",
                     help="C4, N > 1: skip rank 0's un-timed single-GPU pass over the whole table (the strong-scaling base)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: become one (no GPU call in this process), one fresh child per rank
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], timeout_s=args.launch_timeout))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -241,16 +355,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (starts its own ranks) or "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # plumbing only: rendezvous, barrier, max-over-ranks
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rdv = Rendezvous(rank, world) if world > 1 else None   # control channel between the ranks (no torch in any rank)
 
     from gaussian_process_optimization_amd import _lib
     from gaussian_process_optimization_amd.sharded import merge_best
     # rehearsal switch for a one-GPU box: every rank on device 0 (RCCL then refuses the duplicate device and the
-    # exchange falls back to gloo); never set by the driver
+    # exchange falls back to the ranks' control channel); never set by the driver
     dev = 0 if os.environ.get("GPHIP_BENCH_SAME_DEVICE") else local_rank
     h = _lib.Handle(dev)
     h.set_option("emulate_fp64", 0)   # the headline is true fp64 whatever GPHIP_EMULATE_FP64 says (recorded in config)
@@ -279,35 +389,43 @@ def main():
     h.set_candidates(Xs)
     collective, rccl_ranks = None, None
     if world > 1:
-        import torch
         # the one data-path collective: an all-gather of 16 bytes per rank over RCCL.  If the RCCL
-        # communicator cannot be built on this node every rank agrees to fall back to the rendezvous backend (gloo)
-        # for that exchange -- said in the JSON line: such a line is not an RCCL measurement.
-        ok = 1
-        try:
-            uid = [h.comm_unique_id() if rank == 0 else None]
-        except Exception as e:  # noqa: BLE001
-            uid, ok = [None], 0
-            sys.stderr.write("rank %d: RCCL unique id failed: %s\n" % (rank, e))
-        dist.broadcast_object_list(uid, src=0)
-        if uid[0] is None:
-            ok = 0
-        if ok:
+        # communicator cannot be built on this node every rank agrees to exchange the pairs over the control channel
+        # instead -- said in the JSON line: such a line is not an RCCL measurement.
+        ok, uid = 1, None
+        if rank == 0:
             try:
-                h.comm_init(uid[0], rank, world)
+                uid = h.comm_unique_id()
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("rank 0: RCCL unique id failed: %s\n" % e)
+        uid = rdv.bcast(uid)
+        if uid is None:
+            ok = 0
+        else:
+            try:
+                h.comm_init(uid, rank, world)
                 rccl_ranks = h.comm_info()[1]
             except Exception as e:  # noqa: BLE001
                 ok = 0
                 sys.stderr.write("rank %d: RCCL comm init failed: %s\n" % (rank, e))
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        collective = "rccl" if int(flag.item()) == 1 else "gloo (RCCL communicator unavailable: NOT an RCCL measurement)"
+        collective = "rccl" if min(rdv.allgather(ok)) == 1 else \
+            "host sockets between the ranks (RCCL communicator unavailable: NOT an RCCL measurement)"
 
     def barrier():
         h.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if rdv is not None:
+            if collective == "rccl":
+                h.comm_allgather_best(0.0, rank, world)     # an all-gather over the communicator is a barrier of its ranks
+            else:
+                rdv.barrier()
         h.synchronize()
+
+    def max_over_ranks(x):
+        if rdv is None:
+            return x
+        if collective == "rccl":
+            return float(np.max(h.comm_allgather_best(float(x), rank, world)[0]))
+        return max(rdv.allgather(float(x)))
 
     def exchange(val, gidx):
         if world == 1:
@@ -315,12 +433,9 @@ def main():
         if collective == "rccl":
             vals, idxs = h.comm_allgather_best(val, gidx, world)
         else:
-            import torch
-            mine = torch.tensor([val, float(gidx)], dtype=torch.float64)
-            allp = [torch.empty(2, dtype=torch.float64) for _ in range(world)]
-            dist.all_gather(allp, mine)
-            vals = np.array([float(t[0]) for t in allp])
-            idxs = np.array([int(t[1]) for t in allp], dtype=np.int64)
+            pairs = rdv.allgather((float(val), int(gidx)))
+            vals = np.array([p[0] for p in pairs])
+            idxs = np.array([p[1] for p in pairs], dtype=np.int64)
         return merge_best(vals, idxs, -1)
 
     fused = workload == "c3" and not args.separate_calls
@@ -369,15 +484,11 @@ def main():
     phases_timed = {p["name"]: round(p["ms"], 3) for p in h.phases()}   # of the last call of the last timed step
     h.profile(False)
     ranks_agree, rank_records = True, None
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if rdv is not None:
+        elapsed = max_over_ranks(elapsed)
         # every rank merged the same gathered pairs: the winners must be identical (C4; C3 ranks score different tables)
-        rank_records = [None] * world
-        dist.all_gather_object(rank_records, {"rank": rank, "best_row": int(out[1]), "best_value": float(out[2]),
-                                              "lml": float(out[0])})
+        rank_records = rdv.allgather({"rank": rank, "best_row": int(out[1]), "best_value": float(out[2]),
+                                      "lml": float(out[0])})
         if workload == "c4":
             ranks_agree = all(r["best_row"] == rank_records[0]["best_row"] and
                               r["best_value"] == rank_records[0]["best_value"] for r in rank_records)
@@ -470,6 +581,8 @@ def main():
             scaling, value = "strong", job_rate
         cfg.update({"kernel": kname, "noise": 1e-2, "fit": "replicated on every rank (does not shard, SURVEY.md 8e)",
                     "collective": collective, "rccl_comm_ranks": rccl_ranks, "job_iters_per_s": job_rate,
+                    "rccl": {"librccl_mapped": rccl_identity(), "version": h.comm_version()},
+                    "torch_imported": "torch" in sys.modules,
                     "launcher": ("bench.py itself (launch_ranks: %d fresh rank processes, no GPU call in the parent)" % world)
                                 if os.environ.get("GPHIP_BENCH_LAUNCHED") else
                                 ("torch.distributed.run" if world > 1 else "single process"),
@@ -531,9 +644,9 @@ def main():
             result["cpu_baseline"] = cpu_baseline(N, D, 10000, sample_only=args.cpu_baseline_sample)
         print(json.dumps(result))
         sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdv is not None:
+        rdv.barrier()
+        rdv.close()
     h.close()
     if not ranks_agree:
         sys.stderr.write("rank %d: the ranks disagree on the winner: %s\n" % (rank, rank_records))

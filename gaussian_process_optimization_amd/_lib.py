@@ -75,7 +75,23 @@ SIGNATURES = [
     ("gp_comm_info", ctypes.c_int, [_vp, c_int_p, c_int_p]),
     ("gp_comm_allgather_best", ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int64, c_double_p, c_int64_p]),
     ("gp_comm_bcast_fit", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("gp_comm_version", ctypes.c_int, [c_int_p]),
     ("gp_comm_selftest_fit_record", ctypes.c_int, [c_double_p, c_double_p, c_int_p]),
+    ("gp_group_create", ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, c_int_p]),
+    ("gp_group_destroy", ctypes.c_int, [_vp]),
+    ("gp_group_info", ctypes.c_int, [_vp, c_int_p, c_int_p, ctypes.c_char_p, ctypes.c_int]),
+    ("gp_group_member", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_vp)]),
+    ("gp_group_set_data", ctypes.c_int, [_vp, c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    ("gp_group_set_params", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_double]),
+    ("gp_group_set_gower", ctypes.c_int, [_vp, ctypes.c_int, c_int_p, c_double_p]),
+    ("gp_group_set_option", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    ("gp_group_fit", ctypes.c_int, [_vp, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
+    ("gp_group_fmin", ctypes.c_int, [_vp, c_double_p]),
+    ("gp_group_set_candidates", ctypes.c_int, [_vp, c_double_p, ctypes.c_int64]),
+    ("gp_group_acq_argbest", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_int, c_int64_p, c_double_p]),
+    ("gp_group_acq_topk", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                         ctypes.c_double, ctypes.c_int, ctypes.c_int, c_int64_p, c_double_p]),
     ("gp_last_phases", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), c_double_p, c_double_p,
                                       c_double_p]),
     ("gp_profile", ctypes.c_int, [_vp, ctypes.c_int]),
@@ -422,6 +438,11 @@ class Handle(object):
         check(self.lib, self.lib.gp_comm_unique_id(buf), "gp_comm_unique_id")
         return buf.raw
 
+    def comm_version(self):
+        v = ctypes.c_int()
+        check(self.lib, self.lib.gp_comm_version(ctypes.byref(v)), "gp_comm_version")
+        return v.value
+
     def comm_init(self, uid, rank, nranks):
         check(self.lib, self.lib.gp_comm_init(self.h, uid, int(rank), int(nranks)), "gp_comm_init")
 
@@ -449,3 +470,95 @@ class Handle(object):
 
     def comm_bcast_fit(self, root=0):
         check(self.lib, self.lib.gp_comm_bcast_fit(self.h, int(root)), "gp_comm_bcast_fit")
+
+
+class Group(object):
+    """Owns one gp_group_t: the model replicated on ``devices`` (a device may appear more than once), one candidate table
+    split over them, winners merged with NumPy's lowest-index rule (include/gphip.h, gp_group_*)."""
+
+    def __init__(self, devices):
+        self.lib = load()
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        if devs.ndim != 1 or devs.size < 1:
+            raise ValueError("devices must be a non-empty list of HIP device ordinals")
+        h = _vp()
+        check(self.lib, self.lib.gp_group_create(ctypes.byref(h), int(devs.size), devs.ctypes.data_as(c_int_p)),
+              "gp_group_create")
+        self.h = h
+        self.devices = tuple(int(d) for d in devs)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gp_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        n, r = ctypes.c_int(), ctypes.c_int()
+        buf = ctypes.create_string_buffer(256)
+        check(self.lib, self.lib.gp_group_info(self.h, ctypes.byref(n), ctypes.byref(r), buf, 256), "gp_group_info")
+        return dict(ndev=n.value, rccl=bool(r.value), note=buf.value.decode())
+
+    def set_data(self, X, Y):
+        X, Y = as_f64(X, 2), as_f64(Y, 2)
+        if X.shape[0] != Y.shape[0]:
+            raise ValueError("X and Y row counts differ")
+        check(self.lib, self.lib.gp_group_set_data(self.h, dptr(X), dptr(Y), X.shape[0], X.shape[1], Y.shape[1]),
+              "gp_group_set_data")
+        self.N, self.D, self.P = X.shape[0], X.shape[1], Y.shape[1]
+
+    def set_params(self, kernel, ard, variance, lengthscale, noise):
+        ls = as_f64(np.atleast_1d(lengthscale), 1)
+        if ls.size != (self.D if ard else 1):
+            raise ValueError("lengthscale has %d entries, expected %d" % (ls.size, self.D if ard else 1))
+        check(self.lib, self.lib.gp_group_set_params(self.h, int(kernel), int(bool(ard)), float(variance), dptr(ls),
+                                                     float(noise)), "gp_group_set_params")
+
+    def set_gower(self, is_discrete=None, ranges=None):
+        if is_discrete is None:
+            check(self.lib, self.lib.gp_group_set_gower(self.h, 0, None, None), "gp_group_set_gower")
+            return
+        disc = np.ascontiguousarray(is_discrete, dtype=np.int32)
+        rng = as_f64(ranges, 1)
+        check(self.lib, self.lib.gp_group_set_gower(self.h, 1, disc.ctypes.data_as(c_int_p), dptr(rng)), "gp_group_set_gower")
+
+    def set_option(self, name, value):
+        check(self.lib, self.lib.gp_group_set_option(self.h, name.encode(), int(value)), "gp_group_set_option")
+
+    def fit(self, maxtries=5):
+        lml, logdet, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        check(self.lib, self.lib.gp_group_fit(self.h, int(maxtries), ctypes.byref(lml), ctypes.byref(logdet),
+                                              ctypes.byref(jit)), "gp_group_fit")
+        return lml.value, logdet.value, jit.value
+
+    def fmin(self):
+        v = ctypes.c_double()
+        check(self.lib, self.lib.gp_group_fmin(self.h, ctypes.byref(v)), "gp_group_fmin")
+        return v.value
+
+    def set_candidates(self, Xs):
+        Xs = as_f64(Xs, 2)
+        if Xs.shape[1] != self.D:
+            raise ValueError("candidates have %d columns, model has %d" % (Xs.shape[1], self.D))
+        check(self.lib, self.lib.gp_group_set_candidates(self.h, dptr(Xs), Xs.shape[0]), "gp_group_set_candidates")
+        self.M = Xs.shape[0]
+
+    def acq_argbest(self, type_, par, fmin, sense, y_mean=0.0, y_std=1.0):
+        idx, val = ctypes.c_int64(), ctypes.c_double()
+        check(self.lib, self.lib.gp_group_acq_argbest(self.h, int(type_), float(par), float(fmin), float(y_mean),
+                                                      float(y_std), int(sense), ctypes.byref(idx), ctypes.byref(val)),
+              "gp_group_acq_argbest")
+        return idx.value, val.value
+
+    def acq_topk(self, type_, par, fmin, sense, k, y_mean=0.0, y_std=1.0):
+        idx = np.empty(k, dtype=np.int64)
+        val = np.empty(k)
+        check(self.lib, self.lib.gp_group_acq_topk(self.h, int(type_), float(par), float(fmin), float(y_mean), float(y_std),
+                                                   int(sense), int(k), idx.ctypes.data_as(c_int64_p), dptr(val)),
+              "gp_group_acq_topk")
+        return idx, val

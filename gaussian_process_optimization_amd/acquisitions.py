@@ -170,18 +170,38 @@ class AcquisitionBase(object):
         dquotient = (dval * price - val * dprice) / (price ** 2)
         return -quotient * feasible, -dquotient * feasible
 
-    def argbest(self, x, sense=-1):
+    def _group_stage(self, x, devices):
+        """``x`` split over the replicas of the model on ``devices`` (gp_group_*): the group, fmin, normaliser mean / std."""
+        gp = self.model.model
+        grp = gp._device_group(devices)
+        grp.set_candidates(np.atleast_2d(np.asarray(x, dtype=float)))
+        nz = gp.normalizer
+        shift, scale = (0.0, 1.0) if nz is None else (float(nz.mean[0]), float(nz.std[0]))
+        fmin = grp.fmin() if self._rule.needs_fmin else 0.0
+        if self._rule.needs_fmin and nz is not None:
+            fmin = float(nz.inverse_mean(np.array([[fmin]]))[0, 0])
+        return grp, fmin, shift, scale
+
+    def argbest(self, x, sense=-1, devices=None):
         """Row index and value of the best entry of ``acquisition_function(x)``: sense=-1 the smallest (GPyOpt's convention,
-        anchor_points_generator.py:61), sense=+1 the largest (run.py:1241 takes ``np.argmax``).  Ties -> lowest index."""
+        anchor_points_generator.py:61), sense=+1 the largest (run.py:1241 takes ``np.argmax``).  Ties -> lowest index.
+        ``devices=[0, 1, ...]``: the table is split over replicas of the model on those GPUs, still from this one process."""
         if self._device_ok():
+            if devices is not None:
+                grp, fmin, shift, scale = self._group_stage(x, devices)
+                return grp.acq_argbest(self._acq_id, self._par(), fmin, sense, shift, scale)
             gp, fmin, shift, scale = self._device_stage(x)
             return gp._h.acq_argbest(self._acq_id, self._par(), fmin, sense, shift, scale)
         return _pick(self.acquisition_function(x)[:, 0], sense)
 
-    def topk(self, x, k, sense=-1):
+    def topk(self, x, k, sense=-1, devices=None):
         """The ``k`` best rows in order, (indices, values): what ``AnchorPointsGenerator.get`` keeps
-        (anchor_points_generator.py:59-61).  Equal scores lowest index first; fewer than ``k`` rows -> index -1 in the tail."""
+        (anchor_points_generator.py:59-61).  Equal scores lowest index first; fewer than ``k`` rows -> index -1 in the tail.
+        ``devices``: as in ``argbest``."""
         if self._device_ok() and k <= 64:
+            if devices is not None:
+                grp, fmin, shift, scale = self._group_stage(x, devices)
+                return grp.acq_topk(self._acq_id, self._par(), fmin, sense, k, shift, scale)
             gp, fmin, shift, scale = self._device_stage(x)
             return gp._h.acq_topk(self._acq_id, self._par(), fmin, sense, k, shift, scale)
         scores = self.acquisition_function(x)[:, 0]

@@ -12,6 +12,13 @@ extern "C" int gp_comm_unique_id(char *uid128) {
     return 0;
 }
 
+// the version the librccl this process resolved reports about itself (the bench line carries it beside the mapped path)
+extern "C" int gp_comm_version(int *version) {
+    if (!version) return fail(GP_ERR_ARG, "null argument");
+    NCCLCHK(ncclGetVersion(version));
+    return 0;
+}
+
 extern "C" int gp_comm_init(gp_t *g, const char *uid128, int rank, int nranks) {
     if (!g || !uid128) return fail(GP_ERR_ARG, "null argument");
     GP_DEAD_CHECK(g);

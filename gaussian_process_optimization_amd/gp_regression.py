@@ -115,6 +115,8 @@ class GPRegression(Parameterized):
         self.Y_metadata = Y_metadata
         self.max_jitter_tries = 5  # jitchol default, linalg.py:56
         self._h = _lib.Handle(device)
+        self._groups = {}        # replica groups over several devices, keyed by the device tuple (_device_group)
+        self._data_epoch = 0
         self._dirty = True
         self._lml = None
         self._jitter = 0.0
@@ -143,6 +145,7 @@ class GPRegression(Parameterized):
         self.num_data, self.input_dim = self.X.shape
         self.output_dim = self.Y.shape[1]
         self._h.set_data(self.X, self.Y_normalized)
+        self._data_epoch += 1
         self._dirty = True
 
     def set_X(self, X):
@@ -171,6 +174,33 @@ class GPRegression(Parameterized):
             self._h.set_gower(*gower_config(k.space, k.input_dim))
         else:
             self._h.set_gower()
+
+    def _device_group(self, devices):
+        """The model replicated on ``devices`` (HIP ordinals; one may repeat) for scoring ONE candidate table on all of them
+        from this single process (include/gphip.h, gp_group_*; run.py:1240-1241 over the GPUs of the node).  Created on first
+        use, and brought in step -- data, hyper-parameters, Gower set-up, refit of every replica -- whenever the model has
+        changed since the group last fitted."""
+        key = tuple(int(d) for d in devices)
+        grp = self._groups.get(key)
+        if grp is None:
+            grp = self._groups[key] = _lib.Group(key)
+            grp._data_epoch = grp._signature = None
+        k = self.kern
+        gower = gower_config(k.space, k.input_dim) if (k.Gower and k.space is not None) else None
+        signature = (self._data_epoch, k._kernel_id, bool(k.ARD), float(k.variance), tuple(np.ravel(k.lengthscale.values)),
+                     float(self.likelihood.variance), None if gower is None else tuple(map(tuple, gower)))
+        if grp._signature != signature:
+            if grp._data_epoch != self._data_epoch:
+                grp.set_data(self.X, self.Y_normalized)
+                grp._data_epoch = self._data_epoch
+            grp.set_params(k._kernel_id, k.ARD, float(k.variance), k.lengthscale.values, float(self.likelihood.variance))
+            if gower is None:
+                grp.set_gower()
+            else:
+                grp.set_gower(*gower)
+            grp.fit(self.max_jitter_tries)
+            grp._signature = signature
+        return grp
 
     def _predict_resident(self, include_noise):
         """Mean / variance at the staged candidates.  When the model has to be (re)fitted first -- new data or new
@@ -419,4 +449,7 @@ class GPRegression(Parameterized):
         return "\n".join(rows)
 
     def close(self):
+        for grp in self._groups.values():
+            grp.close()
+        self._groups = {}
         self._h.close()

@@ -49,18 +49,21 @@ class Stationary(Parameterized):
     def K(self, X, X2=None):
         """kern.K(X[, X2]) -- stationary.py:107-140, evaluated by the K-build kernels (kern.py:119 is the contract:
         X2 None -> K(X, X) with the diagonal forced to the variance, X2 given -> the [N, M2] cross covariance)."""
-        h = _lib.Handle(0)
-        try:
-            X = _lib.as_f64(X, 2)
-            h.set_data(X, np.zeros((X.shape[0], 1)))
-            h.set_params(self._kernel_id, self.ARD, float(self.variance), self.lengthscale.values, 0.0)
-            if self.Gower and self.space is not None:
-                h.set_gower(*gower_config(self.space, self.input_dim))
-            if X2 is None:
-                return h.kernel_matrix()
-            return h.cross_kernel_matrix(X2)
-        finally:
-            h.close()
+        # one context per kernel object, kept: a loop over kern.K (the kernel contract's caller) does not pay a context's
+        # creation and tear-down per call
+        h = self.__dict__.get("_kh")
+        if h is None or h.h is None:
+            h = self.__dict__["_kh"] = _lib.Handle(0)
+        X = _lib.as_f64(X, 2)
+        h.set_data(X, np.zeros((X.shape[0], 1)))
+        h.set_params(self._kernel_id, self.ARD, float(self.variance), self.lengthscale.values, 0.0)
+        if self.Gower and self.space is not None:
+            h.set_gower(*gower_config(self.space, self.input_dim))
+        else:
+            h.set_gower()
+        if X2 is None:
+            return h.kernel_matrix()
+        return h.cross_kernel_matrix(X2)
 
     def Kdiag(self, X):
         ret = np.empty(X.shape[0])  # stationary.py:195-198

@@ -8,7 +8,8 @@
  * library copies host->device, owns all device memory inside the opaque
  * gp_t, writes results into caller-allocated buffers and keeps no host
  * pointer after returning.  One gp_t per device; calls are synchronous; a
- * gp_t is not thread-safe, distinct gp_t may be used from distinct threads.
+ * gp_t is not thread-safe, distinct gp_t may be used from distinct threads
+ * (gp_group_* below does exactly that for a single-threaded caller).
  *
  * Return codes: 0 = OK; k > 0 = leading minor k of Ky is not positive
  * definite even after the reference's jitter ladder (the host raises
@@ -217,6 +218,8 @@ int gp_comm_destroy(gp_t *gp);
 int gp_comm_info(gp_t *gp, int *rank, int *nranks);
 /* all-gather of one (val, idx) pair per rank: vals[nranks], idxs[nranks]. */
 int gp_comm_allgather_best(gp_t *gp, double val, int64_t idx, double *vals, int64_t *idxs);
+/* ncclGetVersion of the librccl the process resolved (e.g. 22606): recorded by bench.py beside the mapped library path */
+int gp_comm_version(int *version);
 /* the top-k variant ("gather 8 x k pairs"): every rank contributes its k best (val, global idx) pairs
  * (idx < 0 marks an empty slot); all_vals / all_idxs [nranks * k], rank-major. */
 int gp_comm_allgather_topk(gp_t *gp, int k, const double *vals, const int64_t *idxs, double *all_vals,
@@ -229,6 +232,40 @@ int gp_comm_bcast_fit(gp_t *gp, int root);
  * results, and reports the receiver's {jitter, lml, logdet} and {fitted, fmin_valid, wi_valid, invp_valid, lr_valid,
  * predicted}.  Exists because RCCL with 2 ranks cannot run on a 1-GPU box (tests/test_host_logic.py). */
 int gp_comm_selftest_fit_record(const double *root_state, double *state_out, int *flags_out);
+
+/* ---- single-process multi-GPU: a device group ----------------------------------------------------------------------
+ * The reference's BO loop is ONE Python process (GPyOpt/GPyOpt/core/bo.py:73-168, run.py:1207-1258) that scores a candidate
+ * table and takes argmax / argsort()[:5] (run.py:1240-1241, GPyOpt/GPyOpt/optimization/anchor_points_generator.py:59-61).
+ * A group lets that one caller thread use several GPUs of the node: one gp_t per entry of devices[] (the model replicated:
+ * the fit does not shard, every member factors its replica, the devices side by side), the table cut into contiguous row
+ * blocks -- member i of n takes rows [i M/n .., first M % n members one row longer] -- and the per-block winners merged with
+ * NumPy's lowest-index tie rule.  With all devices different the members hold the communicators of ncclCommInitAll and
+ * the winners travel by RCCL all-gather over xGMI (the same gp_comm_allgather_best / _topk a rank of the
+ * one-process-per-GPU layout calls); with a device listed more than once (a one-GPU box rehearsing the logic) the pairs
+ * are merged on the host, which gp_group_info reports.  Calls are synchronous; one group per caller thread. */
+typedef struct gp_group gp_group_t;
+int gp_group_create(gp_group_t **out, int ndev, const int *devices);
+int gp_group_destroy(gp_group_t *grp);
+/* ndev, whether the winners travel by RCCL, and a short note (<= cap bytes) saying which exchange is in use and why */
+int gp_group_info(gp_group_t *grp, int *ndev, int *uses_rccl, char *note, int cap);
+/* member i's context (owned by the group), e.g. for gp_get_alpha / gp_last_phases on one replica */
+int gp_group_member(gp_group_t *grp, int i, gp_t **member);
+/* gp_set_data / gp_set_params / gp_set_gower / gp_set_option applied to every member */
+int gp_group_set_data(gp_group_t *grp, const double *X, const double *Y, int64_t N, int D, int P);
+int gp_group_set_params(gp_group_t *grp, int kernel, int ard, double variance, const double *lengthscale, double noise);
+int gp_group_set_gower(gp_group_t *grp, int enable, const int *is_discrete, const double *range);
+int gp_group_set_option(gp_group_t *grp, const char *name, int64_t value);
+/* gp_fit on every member at once; the scalars are member 0's, and a replica whose LML or jitter differs from member 0's in
+ * any bit fails the call (GP_ERR_STATE) */
+int gp_group_fit(gp_group_t *grp, int maxtries, double *lml, double *logdet, double *jitter_used);
+int gp_group_fmin(gp_group_t *grp, double *fmin);
+/* the WHOLE candidate table Xs[M, D]; each member keeps its block resident */
+int gp_group_set_candidates(gp_group_t *grp, const double *Xs, int64_t M);
+/* gp_acq_argbest / gp_acq_topk over the whole table: idx are rows of the table passed to gp_group_set_candidates */
+int gp_group_acq_argbest(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int sense,
+                         int64_t *idx, double *val);
+int gp_group_acq_topk(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int sense, int k,
+                      int64_t *idx, double *val);
 
 /* ---- measurement ---------------------------------------------------------
  * Phase timings of the last gp_fit / gp_predict measured with HIP events on the

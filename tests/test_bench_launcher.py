@@ -87,3 +87,63 @@ def test_committed_traffic_record_belongs_to_the_current_gemm_source():
     assert src["file"] == "profiles/r03_gemm_traffic.json" and os.path.exists(os.path.join(ROOT, src["file"]))
     # other workloads carry no static figure
     assert bench.static_traffic(8192, 8, 10000) == (None, None)
+
+
+def test_rendezvous_channel_between_rank_processes(tmp_path):
+    """bench.Rendezvous (the torch-free control channel of the multi-rank bench): three rank processes started by
+    launch_ranks find each other through the socket file, broadcast rank 0's 128-byte id, all-gather records in rank order,
+    pass barriers -- and none of them imports torch."""
+    res, _ = _run_launcher(tmp_path, """
+        import json, os, sys
+        sys.path.insert(0, %r)
+        import bench
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        rdv = bench.Rendezvous(rank, world, timeout_s=30)
+        uid = rdv.bcast(bytes(range(128)) if rank == 0 else None)
+        recs = rdv.allgather({"rank": rank, "v": 10.0 * rank})
+        g = rdv.gather(rank * rank)
+        rdv.barrier()
+        out = {"uid_ok": uid == bytes(range(128)), "order": [r["rank"] for r in recs], "max": max(r["v"] for r in recs),
+               "gather": g, "torch": "torch" in sys.modules}
+        rdv.barrier()
+        rdv.close()
+        open(os.path.join(sys.argv[1], "rdv%%d.json" %% rank), "w").write(json.dumps(out))
+    """ % ROOT)
+    assert res["rc"] == 0
+    outs = [json.load(open(tmp_path / ("rdv%d.json" % r))) for r in range(3)]
+    for r, o in enumerate(outs):
+        assert o["uid_ok"] and o["order"] == [0, 1, 2] and o["max"] == 20.0 and o["torch"] is False
+        assert o["gather"] == ([0, 1, 4] if r == 0 else None)
+
+
+def test_launcher_deadline_and_signal_forwarding(tmp_path):
+    """A rank that hangs ends the job at the deadline (exit 124) instead of polling for ever; SIGTERM to the launcher reaches
+    the ranks (they do not outlive it)."""
+    import signal
+    import time
+    child = tmp_path / "hang.py"
+    child.write_text("import os, sys, time\nopen(os.path.join(sys.argv[1], 'pid%s' % os.environ['RANK']), 'w').write(str(os.getpid()))\ntime.sleep(120)\n")
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch_ranks(2, [], child_cmd=[sys.executable, %r, %r], timeout_s=%%s))" % (ROOT, str(child), str(tmp_path)))
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, "-c", code % "2.0"], cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 124 and time.monotonic() - t0 < 30, (out.returncode, out.stderr)
+    for f in ("pid0", "pid1"):
+        os.remove(tmp_path / f)
+    p = subprocess.Popen([sys.executable, "-c", code % "None"], cwd=ROOT)
+    t_end = time.monotonic() + 30
+    while not (os.path.exists(tmp_path / "pid0") and os.path.exists(tmp_path / "pid1")):
+        assert time.monotonic() < t_end
+        time.sleep(0.1)
+    time.sleep(0.3)
+    pids = [int(open(tmp_path / f).read()) for f in ("pid0", "pid1")]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(30) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive

@@ -169,7 +169,8 @@ def test_bench_starts_its_own_ranks_on_one_device():
     """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command): the parent spawns two
     fresh rank processes, they rendezvous over 127.0.0.1, shard ONE candidate table (C4, reduced: N = 2048, 20 000 candidates),
     exchange (best value, global row) pairs and print ONE JSON line from rank 0.  Both ranks sit on device 0 here
-    (GPHIP_BENCH_SAME_DEVICE: a one-GPU box), where RCCL refuses the duplicate device and the exchange is labelled gloo; on an
+    (GPHIP_BENCH_SAME_DEVICE: a one-GPU box), where RCCL refuses the duplicate device and the pairs travel over the ranks' control
+    channel (labelled so); on an
     8-GPU node the only difference is the device index."""
     import json
     import os
@@ -191,7 +192,11 @@ def test_bench_starts_its_own_ranks_on_one_device():
     assert cfg["best_row_matches_single_gpu"] is True
     assert cfg["candidates_total"] == 20000 and cfg["candidates_this_rank"] == 10000
     assert {r["rank"] for r in cfg["rank_records"]} == {0, 1}
-    assert cfg["collective"].startswith("gloo") or cfg["rccl_comm_ranks"] == 2
+    assert cfg["collective"].startswith("host sockets") or cfg["rccl_comm_ranks"] == 2
+    # no rank imported torch; the line says which librccl the process mapped and what version it reports
+    assert cfg["torch_imported"] is False
+    assert cfg["rccl"]["version"] > 20000 and any("rccl" in p for p in cfg["rccl"]["librccl_mapped"])
+    assert not any("torch" in p for p in cfg["rccl"]["librccl_mapped"])
 
 
 def test_bench_line_keeps_the_driver_contract():

@@ -169,3 +169,82 @@ def test_refused_launch_fails_the_call_instead_of_returning_a_stale_result():
     mu2, var2 = h.predict(True)
     assert np.array_equal(mu, mu2) and np.array_equal(var, var2)
     h.close()
+
+
+def _tied_table(seed, M, D, acq_single):
+    """A candidate table whose best row (by ``acq_single(table) -> (row, value)``) also sits in the OTHER half."""
+    table = np.random.default_rng(seed).uniform(0, 1, (M, D))
+    i0, _ = acq_single(table)
+    twin = (i0 + M // 2) % M                      # lands in the other block of a two-way split
+    table[twin] = table[i0]
+    return table, min(i0, twin), max(i0, twin)
+
+
+@pytest.mark.parametrize("devices", [(0, 0), (0,), (0, 0, 0)])
+def test_device_group_equals_single_device(devices):
+    """gp_group_* (one host thread, one context per device) on a one-GPU box: the same device listed twice /
+    three times exercises the split, the per-block scoring of every member and the merge (host merge: no communicator holds a
+    device twice); one device alone takes the RCCL route with a one-rank communicator from ncclCommInitAll.  Winner and
+    top-5 -- with a tie ACROSS blocks among the winners -- equal the single-context results bit for bit; the replicas'
+    LML equals the single context's."""
+    X, Y, _ = O.synthetic_problem(700, 3, 8, seed=17)
+    single = _lib.Handle(0)
+    single.set_data(X, Y)
+    single.set_params(1, 0, 1.2, [0.5], 2e-2)
+    lml = single.fit()[0]
+    fmin = single.fmin()
+
+    def best_single(t):
+        single.set_candidates(t)
+        return single.acq_argbest(_lib.GP_ACQ_EI, 0.01, fmin, -1)
+    table, first, second = _tied_table(5, 1001, 3, best_single)   # 1001 rows: uneven blocks
+    grp = _lib.Group(devices)
+    info = grp.info()
+    assert info["ndev"] == len(devices) and info["rccl"] == (len(set(devices)) == len(devices)), info
+    grp.set_data(X, Y)
+    grp.set_params(1, 0, 1.2, [0.5], 2e-2)
+    assert grp.fit()[0] == lml
+    assert grp.fmin() == fmin
+    grp.set_candidates(table)
+    single.set_candidates(table)
+    for typ, par in ((_lib.GP_ACQ_EI, 0.01), (_lib.GP_ACQ_LCB, 2.0), (_lib.GP_ACQ_MPI, 0.01)):
+        for sense in (-1, +1):
+            assert grp.acq_argbest(typ, par, fmin, sense) == single.acq_argbest(typ, par, fmin, sense)
+            gi, gv = grp.acq_topk(typ, par, fmin, sense, 5)
+            si, sv = single.acq_topk(typ, par, fmin, sense, 5)
+            assert np.array_equal(gi, si) and np.array_equal(gv, sv)
+    gi, gv = grp.acq_topk(_lib.GP_ACQ_EI, 0.01, fmin, -1, 5)
+    assert gi[0] == first and gi[1] == second and gv[0] == gv[1]          # the cross-block tie, lowest row first
+    assert grp.acq_argbest(_lib.GP_ACQ_EI, 0.01, fmin, -1)[0] == first
+    # fewer rows than members: the surplus members sit the round out, the tail of a top-k is marked empty
+    grp.set_candidates(table[:2])
+    single.set_candidates(table[:2])
+    assert grp.acq_argbest(_lib.GP_ACQ_EI, 0.01, fmin, -1) == single.acq_argbest(_lib.GP_ACQ_EI, 0.01, fmin, -1)
+    gi, gv = grp.acq_topk(_lib.GP_ACQ_EI, 0.01, fmin, -1, 4)
+    si, sv = single.acq_topk(_lib.GP_ACQ_EI, 0.01, fmin, -1, 4)
+    assert np.array_equal(gi, si) and np.array_equal(gv, sv) and list(gi[2:]) == [-1, -1]
+    with pytest.raises(ValueError):
+        grp.acq_topk(_lib.GP_ACQ_EI, 0.01, fmin, -1, 65)
+    grp.close()
+    single.close()
+
+
+def test_acquisition_argbest_over_devices_from_one_process():
+    """``Acquisition*.argbest / topk(table, devices=[...])``: what a single-process caller of run.py:1240-1241 /
+    anchor_points_generator.py:59-61 uses to reach several GPUs; follows the model through new data and new hyper-parameters."""
+    X, Y, table = O.synthetic_problem(400, 2, 3000, seed=9, standardize=False)
+    Y = 5 * Y - 2
+    gm = gpo.GPModel(kernel=gpo.kern.RBF(2, 1.0, 0.3), noise_var=0.02, max_iters=0, verbose=False)
+    gm.model = gpo.models.GPRegression(X, Y, gpo.kern.RBF(2, 1.0, 0.3), normalizer=True, noise_var=0.02)
+    for cls in (gpo.AcquisitionEI, gpo.AcquisitionLCB):
+        acq = cls(gm)
+        assert acq.argbest(table, -1, devices=[0, 0]) == acq.argbest(table, -1)
+        i1, v1 = acq.topk(table, 5, -1, devices=[0, 0])
+        i0, v0 = acq.topk(table, 5, -1)
+        assert np.array_equal(i1, i0) and np.array_equal(v1, v0)
+    acq = gpo.AcquisitionEI(gm)
+    gm.model.kern.lengthscale[:] = 0.2                 # new hyper-parameters: the group refits its replicas
+    assert acq.argbest(table, -1, devices=[0, 0]) == acq.argbest(table, -1)
+    gm.model.set_XY(X[:300], Y[:300])                  # new data
+    assert acq.argbest(table, +1, devices=[0, 0]) == acq.argbest(table, +1)
+    gm.model.close()

@@ -291,6 +291,66 @@ def cpu_baseline(N, D, M, sample_only=False):
             "full_size_run": full_size_record()}
 
 
+def small_calls(sizes=(512, 2048, 16384), rows=(1, 5, 1000), reps=20, cpu=True):
+    """One-row call latencies: what the acquisition optimiser hammers between two fits -- scipy L-BFGS-B from each anchor makes
+    single-row calls of acquisition_function_withGradients (GPyOpt/GPyOpt/optimization/optimizer.py:28-61 ->
+    models/gpmodel.py:131-142 -> GPy/GPy/core/gp.py:407-454), the anchor scoring one call of 1000 rows
+    (anchor_points_generator.py:85-98).  Per (N, M): wall time of `gp_set_candidates + gp_predict` and of
+    `gp_set_candidates + gp_acq_grad` (EI) through the C ABI on the fitted model, and beside them the CPU oracle's time for the
+    same two calls (GPModel.predict / acquisition_function_withGradients restated; the model fitted once, Ky^-1 cached as
+    GPy's posterior does) with the BLAS pool limited to this job's CPUs.  D = 8, RBF, noise 1e-2."""
+    from gaussian_process_optimization_amd import _lib
+    h = _lib.Handle(0)
+    h.set_option("emulate_fp64", 0)
+    rows_out = []
+    if cpu:
+        from oracle import cpu_ref as O
+        limiter, cores = O.limit_blas_threads()
+    for N in sizes:
+        D = 8
+        rng = np.random.default_rng(1)
+        X = rng.uniform(0, 1, (N, D))
+        Y = np.sin(2 * np.pi * X).sum(1, keepdims=True) / np.sqrt(D) + 0.05 * rng.standard_normal((N, 1))
+        ls = 0.25 * np.sqrt(D)
+        h.set_data(X, Y)
+        h.set_params(_lib.GP_KERNEL_RBF, 0, 1.0, [ls], 1e-2)
+        h.fit()
+        fmin = h.fmin()
+        gm0 = None
+        if cpu:
+            gp0 = O.OracleGP(X, Y, O.RBF(D, 1.0, ls), 1e-2)
+            gm0 = O.OracleGPModel(gp0)
+            gp0.posterior                         # the fit (pdinv) happens here, outside the timed calls
+            gm0.predict_withGradients(X[:1])      # ... and the lazy Ky^-1 of the posterior
+        for M in rows:
+            Xs = rng.uniform(0, 1, (M, D))
+
+            def dev_predict():
+                h.set_candidates(Xs)
+                return h.predict(True)
+
+            def dev_grad():
+                h.set_candidates(Xs)
+                return h.acq_grad(_lib.GP_ACQ_EI, 0.01, fmin)
+
+            def timed(fn, n):
+                fn()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                return (time.perf_counter() - t0) / n * 1e3
+            rec = {"N": N, "M": M, "gpu_predict_ms": timed(dev_predict, reps), "gpu_acq_grad_ms": timed(dev_grad, reps)}
+            if cpu:
+                ncpu = 3 if N >= 8192 else reps
+                rec["cpu_predict_ms"] = timed(lambda: gm0.predict(Xs), ncpu)
+                rec["cpu_acq_grad_ms"] = timed(lambda: O.acq_EI_withGradients(gm0, Xs, 0.01, fmin), ncpu)
+                rec["cpu_threads"] = int(cores)
+            rows_out.append(rec)
+            sys.stderr.write(json.dumps(rec) + "\n")
+    h.close()
+    return rows_out
+
+
 def full_size_record():
     """The committed one-off run of --cpu-baseline-full on a GPU box's host (static, for orientation beside the sample)."""
     path = os.path.join(ROOT, "profiles", "r02_cpu_baseline_full.json")
@@ -339,12 +399,27 @@ def main():
     ap.add_argument("--separate-calls", action="store_true",
                     help="C3: time gp_fit + gp_predict as two calls instead of the one-call entry point gp_fit_predict")
     ap.add_argument("--no-emulated-line", action="store_true", help="skip the second (int8-emulated) measurement")
+    ap.add_argument("--small-calls", action="store_true",
+                    help="instead of the bench line: one-row call latencies (M = 1, 5, 1000 at N = 512, 2048, 16384) of the "
+                         "device path with the CPU oracle's beside them, as a text table (profiles/r04_small_calls.txt)")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("GPHIP_BENCH_TIMEOUT", "0")) or None,
                     help="--gpus N without a launcher: stop the ranks and exit 124 after this many seconds")
     ap.add_argument("--no-c4-reference", action="store_true",
                     help="C4, N > 1: skip rank 0's un-timed single-GPU pass over the whole table (the strong-scaling base)")
     args = ap.parse_args()
 
+    if args.small_calls:
+        recs = small_calls(cpu=not args.no_cpu_baseline)
+        print("%6s %5s | %12s %12s | %12s %12s | %s" % ("N", "M", "GPU predict", "GPU acq_grad", "CPU predict", "CPU acq_grad",
+                                                        "ms per call; GPU = set_candidates + call through the C ABI"))
+        for r in recs:
+            print("%6d %5d | %12.3f %12.3f | %12s %12s |" % (r["N"], r["M"], r["gpu_predict_ms"], r["gpu_acq_grad_ms"],
+                                                            "%.3f" % r["cpu_predict_ms"] if "cpu_predict_ms" in r else "-",
+                                                            "%.3f" % r["cpu_acq_grad_ms"] if "cpu_acq_grad_ms" in r else "-"))
+        if recs and "cpu_threads" in recs[0]:
+            print("CPU: the oracle (GPy-equivalent NumPy/SciPy path) with %d BLAS threads, model fitted and Ky^-1 cached "
+                  "before the timed calls" % recs[0]["cpu_threads"])
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: become one (no GPU call in this process), one fresh child per rank
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], timeout_s=args.launch_timeout))

@@ -277,6 +277,8 @@ extern "C" int gp_create(gp_t **out, int device) {
     }
     // run an unmodified host program (e.g. the whole GPU test suite) with the emulated contractions on
     if (const char *ev = getenv("GPHIP_EMULATE_FP64")) g->emulate_fp64 = atoi(ev) ? 1 : 0;
+    if (const char *ev = getenv("GPHIP_INNER_TILES")) g->inner_tiles = atoi(ev) == 2 ? 2 : 1;
+    if (const char *ev = getenv("GPHIP_INNER_MIN_ROWS")) g->inner_min_rows = std::max(0, atoi(ev));   // A/B of the in-panel step across unmodified tools
     *out = g;
     return 0;
 }
@@ -341,6 +343,12 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
     if (!strcmp(name, "panel_tiles")) {
         if (value < 1 || value > 64) return fail(GP_ERR_ARG, "panel_tiles out of range");
         g->panel_tiles = (int)value;
+    } else if (!strcmp(name, "inner_tiles")) {
+        if (value != 1 && value != 2) return fail(GP_ERR_ARG, "inner_tiles must be 1 or 2");
+        g->inner_tiles = (int)value;
+    } else if (!strcmp(name, "inner_min_rows")) {
+        if (value < 0) return fail(GP_ERR_ARG, "inner_min_rows < 0");
+        g->inner_min_rows = (int)std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "lookahead")) {
         g->lookahead = value ? 1 : 0;
     } else if (!strcmp(name, "lookahead_min_tiles")) {

@@ -8,6 +8,30 @@
 // A: nt x nt tiles (lower) plus R1 - nt extra row tiles that ride through the panel solves and updates (the RHS rows)
 // side_inv (the model's own factor only): the inverted diagonal panel of each panel is built on the side stream as soon as that
 // panel's columns are final, beside the trailing update and the next panel -- one event record per panel on this stream.
+// One step of the in-panel factorisation starting at tile column j of a panel that ends at J1; returns the next column.
+// Two columns at a time where the panel has them ("inner_tiles" 2, the default): the 256 x 256 diagonal block in ONE launch
+// (potrf_pair_kernel: both diagonal tiles, the tile between them solved and the second one updated inside), ONE launch that
+// solves both tile columns of the rows below (trsm2.hip), ONE K = 256 update of the panel's remaining columns -- three
+// dependent launches per 256 columns where the 128-column step takes six, and contractions twice as long.
+static int chain_step(gp_ctx *g, hipStream_t s, double *A, long lda, int j, int J1, int R1, double *invL, int *info) {
+    if (g->inner_tiles >= 2 && j + 1 < J1 && R1 - (j + 2) >= g->inner_min_rows) {
+        launch_potrf_pair(s, A, lda, j, invL, info);
+        launch_trsm2(s, A, lda, j, invL, j + 2, R1);
+        if (j + 2 < J1)
+            gemm(g, s, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, 2 * GP_TILE,
+                 TileSet{0, R1, j + 2, J1, 1});
+        return j + 2;
+    }
+    launch_potrf_tile(s, A, lda, j, invL, info);
+    // panel solve: A[i, j] <- A[i, j] * inv(L_jj)^T for the row tiles below (and the RHS tile)
+    gemm(g, s, 0, A, lda, A + (long)j * GP_TILE, lda, invL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0, GP_TILE,
+         TileSet{j + 1, R1, j, j + 1, 0}, inplace_opt());
+    // update of the remaining columns of this panel (K = 128)
+    if (j + 1 < J1)
+        gemm(g, s, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE, TileSet{0, R1, j + 1, J1, 1});
+    return j + 1;
+}
+
 void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, int *info, bool side_inv) {
     const int W = g->panel_tiles;
     hipStream_t s = g->s;
@@ -18,16 +42,7 @@ void factor_buf(gp_ctx *g, double *A, long lda, int nt, int R1, double *invL, in
     }
     for (int J0 = 0; J0 < nt; J0 += W) {
         const int J1 = std::min(J0 + W, nt);
-        for (int j = J0; j < J1; ++j) {
-            launch_potrf_tile(s, A, lda, j, invL, info);
-            // panel solve: A[i, j] <- A[i, j] * inv(L_jj)^T for the row tiles below (and the RHS tile)
-            gemm(g, s, 0, A, lda, A + (long)j * GP_TILE, lda, invL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0,
-                 GP_TILE, TileSet{j + 1, R1, j, j + 1, 0}, inplace_opt());
-            // update of the remaining columns of this panel (K = 128)
-            if (j + 1 < J1)
-                gemm(g, s, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE,
-                     TileSet{0, R1, j + 1, J1, 1});
-        }
+        for (int j = J0; j < J1;) j = chain_step(g, s, A, lda, j, J1, R1, invL, info);
         if (side_inv) {
             hipEvent_t eF = la_event(g, EV_CHAIN, J0 / W);
             GP_NOTE(hipEventRecord(eF, s));
@@ -147,14 +162,7 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
     for (int J = 0; J < nJ; ++J) {
         const int J0 = pb[J], J1 = pb[J + 1], J2 = pb[J + 2];
         bool bulk_recorded = false;
-        for (int j = J0; j < J1; ++j) {
-            launch_potrf_tile(sp, A, lda, j, g->dInvL, g->dInfo);
-            gemm(g, sp, 0, A, lda, A + (long)j * GP_TILE, lda, g->dInvL + (long)j * GP_TILE * GP_TILE, GP_TILE, 0,
-                 GP_TILE, TileSet{j + 1, R1, j, j + 1, 0}, inplace_opt());
-            if (j + 1 < J1)
-                gemm(g, sp, 1, A, lda, A + (long)j * GP_TILE, lda, A + (long)j * GP_TILE, lda, 1, GP_TILE,
-                     TileSet{0, R1, j + 1, J1, 1});
-        }
+        for (int j = J0; j < J1;) j = chain_step(g, sp, A, lda, j, J1, R1, g->dInvL, g->dInfo);
         hipEvent_t eF = la_event(g, EV_CHAIN, J);
         GP_NOTE(hipEventRecord(eF, sp));
         const int K = (J1 - J0) * GP_TILE;

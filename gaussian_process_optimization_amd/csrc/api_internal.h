@@ -123,6 +123,9 @@ struct gp_ctx {
     // options
     int panel_tiles = 6;
     int lookahead = 1;
+    int inner_min_rows = 0;         // ... only while at least this many row tiles lie below the pair (below that the 128-column step's shorter launches win)
+    int inner_tiles = 1;            // tile columns per step of the in-panel factorisation (2: potrf_pair_kernel + trsm2 + K = 256 update;
+                                    // measured in round 4: the same wall time as 1 at every size, profiles/r04_pair_step_experiment.txt)
     int lookahead_min_tiles = 40;   // gp_fit: matrices of at most this many tiles (N <= 5120) take the single-stream factorisation
     int reserve_cus = 32;
     long mc_max = 16384;

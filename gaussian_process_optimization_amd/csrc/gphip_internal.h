@@ -109,6 +109,11 @@ void launch_gemm_nt(hipStream_t s, int mode, double *C, long ldc, const double *
 // its inverse (row-major 128x128, lower, zero above) to invL + t*128*128.
 // info: device int, 0 = ok, else 1-based global column of the first non-positive pivot.
 void launch_potrf_tile(hipStream_t s, double *A, long lda, int t, double *invL, int *info);
+// The same for the diagonal tiles t and t + 1 in one launch, including L10 = A10 inv(L00)^T and A11 -= L10 L10^T between them.
+void launch_potrf_pair(hipStream_t s, double *A, long lda, int t, double *invL, int *info);
+// Both tile columns of the rows below a factored pair, one launch: for every 32-row strip of the row tiles [r0, r1)
+//   X0 = A[., t] inv(L_tt)^T;  A[., t+1] -= X0 L[t+1, t]^T;  X1 = A[., t+1] inv(L_t+1,t+1)^T     (in place)
+void launch_trsm2(hipStream_t s, double *A, long lda, int t, const double *invL, int r0, int r1);
 void potrf_set_debug_lds(int bytes);   // test hook: dynamic LDS added to every diagonal-tile launch (a refused launch beyond ~9 KB)
 
 // Ky lower tiles (incl. diagonal tiles in full) from X; padding rows get identity.

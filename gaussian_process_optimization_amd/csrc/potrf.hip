@@ -307,6 +307,8 @@ __device__ __forceinline__ void store_factor_column(double *At, long lda, const 
 
 // Factor + invert tile t of A (see the header).  T: GP_TILE * TS doubles of LDS, Dinv: 8 * DBLK doubles of LDS, zrow: 16 zeros
 // in LDS.  512 threads.
+// PRELOADED: the tile (lower block triangle, diagonal micro blocks in full) already sits in T (potrf_pair_kernel's second tile).
+template <bool PRELOADED = false>
 __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, double *invL, int *info, double *T, double *Dinv,
                                                 const double *zrow) {
     const int tid = threadIdx.x;
@@ -319,7 +321,14 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
 
     // ---- load: block column 0 first (all E(0) needs), the rest of the lower block triangle (diagonal micro blocks in full:
     //      the input is symmetric there) by waves 3..7 while waves 0..2 eliminate micro panel 0 ----
-    {
+    if (PRELOADED) {
+        if (wave < 3) {
+            const int rb0 = 1 + 3 * wave;
+            const int fail = eliminate_panel(T, zrow, 0, rb0, min(3, 8 - rb0), lane);
+            if (wave == 0 && fail >= 0 && lane == 0) atomicCAS(info, 0, t * GP_TILE + fail + 1);
+        }
+        __syncthreads();
+    } else {
         double2_t c0[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -500,18 +509,154 @@ __device__ __forceinline__ void potrf_tile_body(double *A, long lda, int t, doub
     STAMP(31);
 }
 
+// ---- two diagonal tiles per launch -----------------------------------------------------------------------------------------
+// The factorisation's chain costs three dependent launches per 128 columns (this kernel, the panel solve, the update of the
+// panel's remaining columns).  potrf_pair_kernel takes the 256 x 256 diagonal block [A00; A10 A11] in ONE launch and ONE
+// workgroup, the tile resident in LDS throughout:
+//   body(t)        A00 = L00 L00^T, inv00 = L00^-1                                   (as potrf_tile_kernel)
+//   L10 = A10 inv00^T    every wave takes a 16-row block of A10: its operand fragments straight from global memory (32 bytes
+//                        contiguous per lane and k block), inv00 from where body(t) left it in LDS (transposed in T's upper
+//                        blocks, diagonal micro blocks in Dinv); 8 accumulators per wave, 144 matrix instructions
+//   A11 -= L10 L10^T     L10 goes to LDS (and to HBM) and the lower block triangle of A11 takes the rank-128 update, 4-5
+//                        micro blocks per wave, A11's old values as the accumulators' initial values
+//   body(t+1)      with the tile already in LDS
+// after which ONE launch solves both tile columns of the rows below (trsm2.hip) and ONE K = 256 launch updates the rest of the
+// panel: half the dependent launches per column, and products twice as long.
+__device__ __forceinline__ void pair_offdiag_solve(const double *A10, long lda, double *T, const double *Dinv, int wave, int li,
+                                                   int lg, double4_t (&acc)[8]) {
+    // A fragments of this wave's 16 rows: step e of k block Kb contracts k = 16 Kb + 4 lg + e (the same map on the B side); the
+    // fragments of k block Kb + 1 are fetched while block Kb multiplies
+    const double *ap = A10 + (long)(16 * wave + li) * lda + 4 * lg;
+    double2_t n0 = *(const double2_t *)ap, n1 = *(const double2_t *)(ap + 2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int Kb = 0; Kb < 8; ++Kb) {
+        const double a[4] = {n0[0], n0[1], n1[0], n1[1]};
+        if (Kb < 7) {
+            n0 = *(const double2_t *)(ap + 16 * (Kb + 1));
+            n1 = *(const double2_t *)(ap + 16 * (Kb + 1) + 2);
+        }
+        // B[k][n] = inv00[16 Jc + n][16 Kb + k]: Kb < Jc parked at T[(16 Kb + k) TS + 16 Jc + n], Kb == Jc in Dinv[Jc][n][k];
+        // two column blocks at a time: two independent accumulation chains
+#pragma unroll
+        for (int Jc = Kb; Jc < 8; Jc += 2) {
+            double b0[4], b1[4];
+            if (Jc == Kb) {
+                const double *q = Dinv + Jc * DBLK + li * DS + 4 * lg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b0[e] = q[e];
+            } else {
+                const double *q = T + (16 * Kb + 4 * lg) * TS + 16 * Jc + li;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b0[e] = q[e * TS];
+            }
+            if (Jc + 1 < 8) {
+                const double *q = T + (16 * Kb + 4 * lg) * TS + 16 * (Jc + 1) + li;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b1[e] = q[e * TS];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], b0[e], acc[Jc], 0, 0, 0);
+                if (Jc + 1 < 8) acc[Jc + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], b1[e], acc[Jc + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every block's operand reads to the top)
+        }
+    }
+}
+
+// micro block b of the lower block triangle enumerated row by row: (0,0), (1,0), (1,1), (2,0), ...
+__device__ __forceinline__ void tri_block(int b, int &I, int &J) {
+    I = 0;
+    while ((I + 1) * (I + 2) / 2 <= b) ++I;
+    J = b - I * (I + 1) / 2;
+}
+
+__global__ __launch_bounds__(512) void potrf_pair_kernel(double *A, long lda, int t, double *invL, int *info) {
+    __shared__ __attribute__((aligned(16))) double T[GP_TILE * TS];
+    __shared__ __attribute__((aligned(16))) double Dinv[8 * DBLK];
+    __shared__ __attribute__((aligned(16))) double zrow[16];
+    if (threadIdx.x < 16) zrow[threadIdx.x] = 0.0;
+    potrf_tile_body<false>(A, lda, t, invL, info, T, Dinv, zrow);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    double *A10 = A + (long)(t + 1) * GP_TILE * lda + (long)t * GP_TILE;
+    double *A11 = A10 + GP_TILE;
+    // this wave's micro blocks of A11 (blocks wave, wave + 8, ... of the 36 of the lower block triangle, diagonal ones in full)
+    // are requested now and arrive while L10 is computed
+    double4_t upd[5];
+    int bi[5], bj[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int b = wave + 8 * q;
+        tri_block(b < 36 ? b : 0, bi[q], bj[q]);
+        if (b < 36) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) upd[q][r] = A11[(long)(16 * bi[q] + 4 * r + lg) * lda + 16 * bj[q] + li];
+        }
+    }
+    // ---- L10 = A10 inv00^T (the inverse's last level was stored from T / Dinv by every thread: they are complete and at rest) ----
+    double4_t acc[8];
+    pair_offdiag_solve(A10, lda, T, Dinv, wave, li, lg, acc);
+    __syncthreads();                       // every wave has read the inverse out of T
+#pragma unroll
+    for (int Jc = 0; Jc < 8; ++Jc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(16 * wave + 4 * r + lg) * TS + 16 * Jc + li] = acc[Jc][r];
+    __syncthreads();
+    // L10 leaves for HBM (16-byte stores) while the update below runs
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 512 * q, r = e >> 6, c = (e & 63) * 2;
+        *(double2_t *)(A10 + (long)r * lda + c) = *(const double2_t *)(T + r * TS + c);
+    }
+    // ---- A11 -= L10 L10^T on the lower block triangle ----
+#pragma unroll 1
+    for (int Kb = 0; Kb < 8; ++Kb) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (wave + 8 * q < 36) {
+                const double *ap = T + (16 * bi[q] + li) * TS + 16 * Kb + 4 * lg;
+                const double *bp = T + (16 * bj[q] + li) * TS + 16 * Kb + 4 * lg;
+                const double2_t a0 = *(const double2_t *)ap, a1 = *(const double2_t *)(ap + 2);
+                const double2_t b0 = *(const double2_t *)bp, b1 = *(const double2_t *)(bp + 2);
+                upd[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], upd[q], 0, 0, 1);
+                upd[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], upd[q], 0, 0, 1);
+                upd[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], upd[q], 0, 0, 1);
+                upd[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], upd[q], 0, 0, 1);
+            }
+        }
+    }
+    __syncthreads();                       // every wave has read L10 out of T
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        if (wave + 8 * q < 36) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(16 * bi[q] + 4 * r + lg) * TS + 16 * bj[q] + li] = upd[q][r];
+        }
+    __syncthreads();
+    potrf_tile_body<true>(A, lda, t + 1, invL, info, T, Dinv, zrow);
+}
+
 __global__ __launch_bounds__(512) void potrf_tile_kernel(double *A, long lda, int t, double *invL, int *info) {
     __shared__ __attribute__((aligned(16))) double T[GP_TILE * TS];
     __shared__ __attribute__((aligned(16))) double Dinv[8 * DBLK];
     __shared__ __attribute__((aligned(16))) double zrow[16];   // the row of zeros E's idle lanes read
     if (threadIdx.x < 16) zrow[threadIdx.x] = 0.0;             // (visible after the first barrier of the body)
-    potrf_tile_body(A, lda, t, invL, info, T, Dinv, zrow);
+    potrf_tile_body<false>(A, lda, t, invL, info, T, Dinv, zrow);
 }
 
 // Test hook (option "debug_potrf_lds"): extra dynamic LDS requested with every diagonal-tile launch.  Beyond what the CU has
 // left beside the kernel's 151 KB of static LDS the launch is REFUSED -- which is what the launch checks are there to catch.
 static int g_debug_lds = 0;
 void potrf_set_debug_lds(int bytes) { g_debug_lds = bytes; }
+
+void launch_potrf_pair(hipStream_t s, double *A, long lda, int t, double *invL, int *info) {
+    GP_LAUNCH(potrf_pair_kernel, dim3(1), dim3(512), (size_t)g_debug_lds, s, A, lda, t, invL, info);
+}
 
 void launch_potrf_tile(hipStream_t s, double *A, long lda, int t, double *invL, int *info) {
     GP_LAUNCH(potrf_tile_kernel, dim3(1), dim3(512), (size_t)g_debug_lds, s, A, lda, t, invL, info);

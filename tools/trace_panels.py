@@ -17,7 +17,7 @@ for r in chain:
     if "potrf" in r["Kernel_Name"]:
         if npot and npot % W == 0:
             panels.append(cur); cur = []
-        npot += 1
+        npot += 2 if "pair" in r["Kernel_Name"] else 1     # potrf_pair_kernel factors two tile columns
     cur.append(r)
 panels.append(cur)
 others = [r for r in last if r["Queue_Id"] != chain_q and E(r) - S(r) > 100]

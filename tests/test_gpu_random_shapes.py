@@ -1,6 +1,6 @@
 """GPU: seeded random sweep over shapes, kernels and blocking options against the live oracle.
 
-Every case draws (N, D, M, P, kernel, ARD, noise, panel_tiles, mc_max, pipelined?) and compares LML, alpha,
+Every case draws (N, D, M, P, kernel, ARD, noise, panel_tiles, mc_max, pipelined?; every third one with inner_tiles = 2) and compares LML, alpha,
 posterior mean / variance / full covariance, hyper-gradients, predictive gradients and the three acquisitions
 with the oracle (tolerances as in test_gpu_parity.py: LML 1e-8 rel, posterior 1e-6 rel, gradients 1e-6 of scale).
 The blocking options change the launch structure (panel width, candidate chunking, pipelining), never the results
@@ -67,6 +67,8 @@ def test_random_case(h, case):
     p = gp.posterior
     h.set_option("panel_tiles", pt)
     h.set_option("mc_max", mc)
+    # every third case factors two tile columns per step of the in-panel factorisation (potrf_pair_kernel + trsm2_kernel)
+    h.set_option("inner_tiles", 2 if i % 3 == 0 else 1)
     try:
         h.set_data(X, Y)
         h.set_params(0 if kname == "rbf" else 1, ard, var, ls, noise)
@@ -112,3 +114,4 @@ def test_random_case(h, case):
     finally:
         h.set_option("panel_tiles", 6)
         h.set_option("mc_max", 16384)
+        h.set_option("inner_tiles", 1)

@@ -248,3 +248,32 @@ def test_acquisition_argbest_over_devices_from_one_process():
     gm.model.set_XY(X[:300], Y[:300])                  # new data
     assert acq.argbest(table, +1, devices=[0, 0]) == acq.argbest(table, +1)
     gm.model.close()
+
+
+@pytest.mark.parametrize("N", [2048, 5000])
+def test_pair_step_factorisation_matches_the_tile_step(N):
+    """Option inner_tiles = 2 (potrf_pair_kernel: two diagonal tiles per launch with the tile between them solved and the second
+    one updated inside; trsm2_kernel: both tile columns of the rows below in one launch; one K = 256 update) against the
+    128-column step on the single-stream (N = 2048) and the look-ahead (N = 5000, 40 tiles: ragged last panel) schedulers:
+    the same factor to rounding (another order of the same sums), LML 1e-12, and bitwise reproducible from run to run."""
+    X, Y, Xs = O.synthetic_problem(N, 4, 300, seed=3)
+    h = _lib.Handle(0)
+    h.set_option("emulate_fp64", 0)
+    h.set_option("lookahead_min_tiles", 20)
+    h.set_data(X, Y)
+    h.set_params(0, 0, 1.3, [0.45], 1e-2)
+    h.set_candidates(Xs)
+    lml1 = h.fit()[0]
+    L1 = h.chol()
+    mu1, v1 = h.predict(True)
+    h.set_option("inner_tiles", 2)
+    lml2 = h.fit()[0]
+    L2 = h.chol()
+    mu2, v2 = h.predict(True)
+    assert abs(lml2 - lml1) <= 1e-12 * abs(lml1)
+    assert np.max(np.abs(L2 - L1)) <= 1e-11 * np.max(np.abs(L1))
+    assert relmax(mu2, mu1) < 1e-9 and relmax(v2, v1) < 1e-9
+    assert h.fit()[0] == lml2 and np.array_equal(h.chol(), L2)
+    (lml3, _, _), mu3, v3 = h.fit_predict(True)                      # the one-call entry point takes the same steps
+    assert lml3 == lml2 and np.array_equal(mu3, mu2) and np.array_equal(v3, v2)
+    h.close()

@@ -391,6 +391,12 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->stagger = (int)value;
     } else if (!strcmp(name, "supertile")) {
         if (value < 0 || value > 64) return fail(GP_ERR_ARG, "supertile out of range");
+        if (g->supertile != (int)value) {   // the cached tile orders belong to the old edge
+            HIPCHK(hipSetDevice(g->device));
+            HIPCHK(hipDeviceSynchronize());
+            for (auto &kv : g->tile_lists) hipFree(kv.second);
+            g->tile_lists.clear();
+        }
         g->supertile = (int)value;
     } else if (!strcmp(name, "reserve_cus")) {
         if (value != g->bulk_reserved)
@@ -414,6 +420,10 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "debug_potrf_lds")) {
         if (value < 0 || value > (1 << 20)) return fail(GP_ERR_ARG, "debug_potrf_lds out of range");
         potrf_set_debug_lds((int)value);   // process-wide test hook: forces refused diagonal-tile launches (tests/test_gpu_round4.py)
+    } else if (!strcmp(name, "small_m")) {
+        if (value < 0 || value > 64) return fail(GP_ERR_ARG, "small_m out of range (0..64)");
+        g->small_m = value;
+        g->predicted = false;
     } else if (!strcmp(name, "mc_max")) {
         if (value < GP_TILE) return fail(GP_ERR_ARG, "mc_max < 128");
         g->mc_max = round_up(value, GP_TILE);

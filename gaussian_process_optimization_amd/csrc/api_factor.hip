@@ -529,7 +529,10 @@ extern "C" int gp_fit_predict(gp_t *g, int maxtries, int include_noise, double *
     HIPCHK(hipSetDevice(g->device));
     const int nt = (int)(g->Npad / GP_TILE);
     // the emulated candidate solve runs after the factorisation (its residue planes of L need the complete factor)
-    const bool can_pipe = g->lookahead && nt > g->panel_tiles && round_up(g->M, GP_TILE) <= g->mc_max && !g->emulate_fp64;
+    // (a handful of candidates take the matrix-vector solve of gp_predict after the factorisation: both entry points then
+    // return the same bits)
+    const bool can_pipe = g->lookahead && nt > g->panel_tiles && round_up(g->M, GP_TILE) <= g->mc_max && !g->emulate_fp64 &&
+                          g->M > g->small_m;
     int rc;
     if (can_pipe) {
         if ((rc = fit_impl(g, maxtries, 1, include_noise))) return rc;

@@ -107,7 +107,10 @@ int run_predict_grad(gp_ctx *g) {
         const int mt = (int)(mcpad / GP_TILE);
         launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, N, Npad, g->kp);
         // beta = K(Xs, X) Ky^-1   (gp.py:451-452; Ky^-1 symmetric => rows of Wi serve as the B operand)
-        gemm(g, g->s, 0, g->dCov, Npad, g->dT, Npad, g->dWi, Npad, 1, (int)Npad, TileSet{0, mt, 0, nt, 0});
+        if (M <= g->small_m)   // a handful of rows: row dots with Ky^-1, one read of it (smallm.hip)
+            launch_small_wi_product(g->s, g->dWi, Npad, Npad, g->dT, Npad, (int)mc, g->dCov, Npad);
+        else
+            gemm(g, g->s, 0, g->dCov, Npad, g->dT, Npad, g->dWi, Npad, 1, (int)Npad, TileSet{0, mt, 0, nt, 0});
         launch_predict_grad(g->s, g->dXs + m0 * g->D, mc, g->dX, N, g->kp, g->dAlpha, Npad, g->P, g->dCov, Npad,
                             g->dDm + m0 * g->D * g->P, g->dDv + m0 * g->D);
     }

@@ -129,6 +129,7 @@ struct gp_ctx {
     int lookahead_min_tiles = 40;   // gp_fit: matrices of at most this many tiles (N <= 5120) take the single-stream factorisation
     int reserve_cus = 32;
     long mc_max = 16384;
+    long small_m = 8;        // up to this many candidates take the matrix-vector solve (smallm.hip) instead of the tile path
     // profiling
     Phase phases[MAX_PHASES];
     int nphases = 0;
@@ -274,7 +275,7 @@ int ensure_panel_inv(gp_ctx *g);
 void solve_rows(gp_ctx *g, double *T, double *S, int mt, int trapezoid, int J_from = 0);
 int solve_rows_rns(gp_ctx *g, double *T, double *S, int mt, const RnsSolveOpt &opt = RnsSolveOpt());
 int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise);
-int run_predict(gp_ctx *g, int include_noise);
+int run_predict(gp_ctx *g, int include_noise, bool tiles_only = false);   // tiles_only: never the small-M path (the caller uses dT2 as a padded tile operand)
 int ensure_out(gp_ctx *g);
 int run_acq(gp_ctx *g, int type, double par, double fmin, double y_mean, double y_std);
 struct LpBatch { double *X = nullptr, *r = nullptr, *s = nullptr; };

@@ -18,7 +18,7 @@ extern "C" int gp_set_candidates(gp_t *g, const double *Xs, int64_t M) {
     return 0;
 }
 
-int run_predict(gp_ctx *g, int include_noise) {
+int run_predict(gp_ctx *g, int include_noise, bool tiles_only) {
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     HIPCHK(hipSetDevice(g->device));
@@ -30,6 +30,23 @@ int run_predict(gp_ctx *g, int include_noise) {
     if ((rc = ensure_panel_inv(g))) return rc;
     if ((rc = dev_realloc(&g->dT, &g->capT, mc_max * Npad))) return rc;
     if ((rc = dev_realloc(&g->dT2, &g->capT2, mc_max * Npad))) return rc;
+    if (M <= g->small_m && !tiles_only) {
+        // A handful of rows (the acquisition optimiser's one-row calls): the solve as matrix-vector work bound by ONE read of
+        // L (smallm.hip) instead of ~45 dependent tile launches; always true fp64.
+        int ph = phase_begin(g, "cross_k", 0.0, 8.0 * (double)(N + M) * g->D + 8.0 * (double)N * M);
+        launch_cross_k(g->s, g->dT, Npad, g->dXs, M, round_up(M, GP_TILE), g->dX, g->N, Npad, g->kp);
+        phase_end(g, ph);
+        ph = phase_begin(g, "cand_solve_rows", (double)N * N * M, 8.0 * (double)N * N / 2);
+        launch_small_forward_solve(g->s, g->dA, Npad, g->dInvP, g->invp_W, Npad, g->dT, g->dT2, Npad, (int)M);
+        phase_end(g, ph);
+        ph = phase_begin(g, "reduce", 0.0, 8.0 * (double)N * M);
+        launch_predict_reduce(g->s, g->dT2, Npad, M, N, g->dA + Npad * Npad, Npad, P, g->kp.variance,
+                              include_noise ? g->noise : 0.0, g->dMean, g->dVar);
+        phase_end(g, ph);
+        g->predicted = true;
+        g->predicted_noise = include_noise ? 1 : 0;
+        return 0;
+    }
     for (long m0 = 0; m0 < M; m0 += mc_max) {
         const long mc = std::min(mc_max, M - m0);
         const long mcpad = round_up(mc, GP_TILE);
@@ -237,7 +254,7 @@ extern "C" int gp_predict_full_cov(gp_t *g, int include_noise, double *mean, dou
     if (Mpad > g->mc_max) return fail(GP_ERR_ARG, "full covariance needs M <= mc_max (%ld)", g->mc_max);
     int rc;
     if ((rc = ensure_out(g))) return rc;
-    if ((rc = run_predict(g, include_noise))) return rc;  // leaves S = K(Xs,X) L^-T in dT2 (single chunk)
+    if ((rc = run_predict(g, include_noise, true))) return rc;  // leaves S = K(Xs,X) L^-T in dT2 (single chunk, zero padding rows: tile path)
     if ((rc = dev_realloc(&g->dCov, &g->capCov, std::max(g->capCov, Mpad * Mpad)))) return rc;
     const int mt = (int)(Mpad / GP_TILE);
     launch_kbuild(g->s, g->dCov, Mpad, g->dXs, M, Mpad, g->kp, 0.0, 1);  // K(Xs, Xs)
@@ -304,7 +321,7 @@ extern "C" int gp_posterior_samples(gp_t *g, int include_noise, const double *Z,
     if (Mpad > g->mc_max) return fail(GP_ERR_ARG, "posterior samples need M <= mc_max (%ld)", g->mc_max);
     int rc;
     if ((rc = ensure_out(g))) return rc;
-    if ((rc = run_predict(g, include_noise))) return rc;  // S_c = K(Xs,X) L^-T in dT2 (single chunk), mean in dMean
+    if ((rc = run_predict(g, include_noise, true))) return rc;  // S_c = K(Xs,X) L^-T in dT2 (single chunk, zero padding rows: tile path), mean in dMean
     // dCov: [cov Mpad x Mpad][Z^T Spad x Mpad][dev Spad x Mpad]; the inverted diagonal tiles go to dT (free now)
     if ((rc = dev_realloc(&g->dCov, &g->capCov, std::max(g->capCov, Mpad * Mpad + 2 * Spad * Mpad)))) return rc;
     double *C = g->dCov, *Zd = g->dCov + Mpad * Mpad, *Dv = Zd + Spad * Mpad;

@@ -154,6 +154,14 @@ void launch_acq(hipStream_t s, int type, double par, double fmin, double y_mean,
 void launch_argbest(hipStream_t s, const double *v, long n, int sense, double *best_val, long long *best_idx,
                     double *scratch_val, long long *scratch_idx);
 
+// ---- smallm.hip: a handful of candidate rows as matrix-vector work (the acquisition optimiser's one-row calls) ----------
+// S[m, :] = T[m, :] L^-T for m < M by forward substitution over the panels (T consumed), inverted diagonal panels invP (W tiles)
+void launch_small_forward_solve(hipStream_t s, const double *L, long lda, const double *invP, int W, long Npad, double *T,
+                                double *S, long ldt, int M);
+// beta[m, :] = Kx[m, :] Wi for m < M (Wi symmetric, Npad x Npad)
+void launch_small_wi_product(hipStream_t s, const double *Wi, long ldw, long Npad, const double *Kx, long ldk, int M,
+                             double *beta, long ldb);
+
 // ---- grad.hip ---------------------------------------------------------------------------------
 #define GP_GRAD_CH 16
 #define GP_GRAD_NACC (GP_GRAD_CH + 2)

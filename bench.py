@@ -367,7 +367,7 @@ def static_traffic(N, D, M):
     """HBM-side traffic of the dominant kernel from the committed PMC passes of THIS command (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, tools/pmc_traffic.py).  Not measured by this run: carried with its
     provenance and dropped when gemm.hip has changed since the passes were taken."""
-    tpath = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")
     if not os.path.exists(tpath) or (N, D, M) != (16384, 8, 10000):
         return None, None
     with open(tpath) as f:
@@ -377,7 +377,7 @@ def static_traffic(N, D, M):
     if tj.get("gemm_hip_sha256_16") != sha:
         return None, {"static": True, "dropped": "gemm.hip changed since the counter passes (%s != %s)"
                                                  % (tj.get("gemm_hip_sha256_16"), sha)}
-    return tj["traffic_bytes_per_launch"], {"static": True, "file": "profiles/r03_gemm_traffic.json",
+    return tj["traffic_bytes_per_launch"], {"static": True, "file": "profiles/r04_gemm_traffic.json",
                                             "kernel": GEMM_SYMBOL, "launches": tj["launches"],
                                             "gemm_hip_sha256_16": sha,
                                             "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch")}
@@ -669,7 +669,10 @@ def main():
                                    "region (the per-phase rates below come from it)",
                     "cholesky_tflops": chol["flops"] / chol["ms"] / 1e9,
                     "cholesky_frac_of_fp64_mfma_peak": chol["flops"] / chol["ms"] / 1e9 / FP64_MFMA_PEAK_TFLOPS,
-                    "cand_solve_tflops": solve["flops"] / solve["ms"] / 1e9})
+                    "cand_solve_tflops": solve["flops"] / solve["ms"] / 1e9,
+                    # the same phase counting what it executes: N^2 M plus the products with the inverted diagonal panels
+                    # (M N x panel width; 768 columns by default) -- the rate to hold against the GEMM kernel's own
+                    "cand_solve_executed_tflops": solve["flops"] * (1.0 + 768.0 / N) / solve["ms"] / 1e9})
         result = {
             "metric": "GP fit+predict iters/sec at N=%d D=%d" % (N, D),
             "value": value, "unit": "fit+predict iters/s",
@@ -681,7 +684,8 @@ def main():
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_provenance": traffic_src,
-                         "note": ("HIP events bracket every launch of this kernel symbol INSIDE the timed region (~29 per step), "
+                         "note": ("HIP events bracket every launch of this kernel symbol INSIDE the timed region (%.0f per step), "
+                                  % (gs["launches"] / max(args.steps, 1)) +
                                   "on the stream each is launched on.  In gp_fit_predict a few candidate-update launches and "
                                   "the trailing updates of the factorisation's tail run concurrently: a launch's duration "
                                   "includes the time it shares the chip; achieved_while_running = the same flops / the union "
@@ -711,7 +715,7 @@ def main():
             "kbuild": {"bound": "hbm", "kernel": "kbuild_kernel (+ set_rhs_kernel: the 'kbuild' phase of gp_fit, HIP events)",
                        "algorithmic_bytes": kb["bytes"], "ms": kb["ms"], "achieved": kb_gbs, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": kb_gbs / HBM_PEAK_GBS,
-                       "counter_evidence": "profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"},
+                       "counter_evidence": "profiles/r04_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"},
         }
         if emulated is not None:
             result["emulated_fp64_second_line"] = emulated

@@ -71,7 +71,7 @@ def test_plain_invocation_with_gpus_gt_1_becomes_the_launcher():
 
 
 def test_committed_traffic_record_belongs_to_the_current_gemm_source():
-    """`roofline.traffic` is carried from committed counter passes (profiles/r03_gemm_traffic.json) and dropped when gemm.hip has
+    """`roofline.traffic` is carried from committed counter passes (profiles/r04_gemm_traffic.json) and dropped when gemm.hip has
     changed since they were taken: the committed record must match the committed kernel source, or the bench line silently loses
     the field."""
     import hashlib
@@ -84,7 +84,7 @@ def test_committed_traffic_record_belongs_to_the_current_gemm_source():
     assert traffic is not None and traffic > 1e9, src
     gem = os.path.join(ROOT, "gaussian_process_optimization_amd", "csrc", "gemm.hip")
     assert src["gemm_hip_sha256_16"] == hashlib.sha256(open(gem, "rb").read()).hexdigest()[:16]
-    assert src["file"] == "profiles/r03_gemm_traffic.json" and os.path.exists(os.path.join(ROOT, src["file"]))
+    assert src["file"] == "profiles/r04_gemm_traffic.json" and os.path.exists(os.path.join(ROOT, src["file"]))
     # other workloads carry no static figure
     assert bench.static_traffic(8192, 8, 10000) == (None, None)
 

@@ -90,6 +90,9 @@ SIGNATURES = [
     ("gp_group_set_candidates", ctypes.c_int, [_vp, c_double_p, ctypes.c_int64]),
     ("gp_group_acq_argbest", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                             ctypes.c_double, ctypes.c_int, c_int64_p, c_double_p]),
+    ("gp_group_acq_lp_argbest", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                               ctypes.c_double, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, c_double_p,
+                                               ctypes.c_int, c_int64_p, ctypes.c_int, c_int64_p, c_double_p]),
     ("gp_group_acq_topk", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, c_int64_p, c_double_p]),
     ("gp_last_phases", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), c_double_p, c_double_p,
@@ -553,6 +556,21 @@ class Group(object):
         check(self.lib, self.lib.gp_group_acq_argbest(self.h, int(type_), float(par), float(fmin), float(y_mean),
                                                       float(y_std), int(sense), ctypes.byref(idx), ctypes.byref(val)),
               "gp_group_acq_argbest")
+        return idx.value, val.value
+
+    def acq_lp_argbest(self, type_, par, fmin, transform, sense, Xb=None, r_x0=None, s_x0=None, exclude=(), y_mean=0.0,
+                       y_std=1.0):
+        if Xb is None:
+            keep, nb, pX, pr, ps = None, 0, None, None, None
+        else:
+            Xb, r, sc = as_f64(np.atleast_2d(Xb), 2), as_f64(np.atleast_1d(r_x0), 1), as_f64(np.atleast_1d(s_x0), 1)
+            keep, nb, pX, pr, ps = (Xb, r, sc), Xb.shape[0], dptr(Xb), dptr(r), dptr(sc)
+        ex = np.asarray(list(exclude), dtype=np.int64)
+        idx, val = ctypes.c_int64(), ctypes.c_double()
+        check(self.lib, self.lib.gp_group_acq_lp_argbest(self.h, int(type_), float(par), float(fmin), float(y_mean),
+                                                         float(y_std), int(transform), pX, nb, pr, ps, int(sense),
+                                                         ex.ctypes.data_as(c_int64_p), int(ex.size), ctypes.byref(idx),
+                                                         ctypes.byref(val)), "gp_group_acq_lp_argbest")
         return idx.value, val.value
 
     def acq_topk(self, type_, par, fmin, sense, k, y_mean=0.0, y_std=1.0):

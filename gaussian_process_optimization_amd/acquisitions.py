@@ -391,9 +391,16 @@ class AcquisitionLP(AcquisitionBase):
             grad = grad - self._penalty_slope(x)
         return self.acquisition_function(x), grad
 
-    def argbest(self, x, sense=+1, exclude=()):
-        """Arg-best of ``acquisition_function(x)`` with the rows in ``exclude`` masked out (run.py:1241,1249-1252)."""
+    def argbest(self, x, sense=+1, exclude=(), devices=None):
+        """Arg-best of ``acquisition_function(x)`` with the rows in ``exclude`` masked out (run.py:1241,1249-1252).
+        ``devices``: the table split over replicas of the model on those GPUs, from this one process (gp_group_*)."""
         if self._lp_device_ok():
+            if devices is not None:
+                base = self.acq
+                grp, fmin, shift, scale = base._group_stage(x, devices)
+                return grp.acq_lp_argbest(base._acq_id, base._par(), fmin, 1 if self.transform == 'softplus' else 0, sense,
+                                          Xb=self.X_batch, r_x0=self.r_x0, s_x0=self.s_x0, exclude=exclude, y_mean=shift,
+                                          y_std=scale)
             h, head, batch = self._lp_call(x)
             return h.acq_lp_argbest(head[0], head[1], head[2], head[3], sense, exclude=exclude, **batch)
         scores = np.array(self.acquisition_function(x), dtype=float)
@@ -448,16 +455,16 @@ class LocalPenalization(object):
         lp.update_batches(None, None, None)
         return batch
 
-    def compute_batch_from_table(self, table, sense=+1):
+    def compute_batch_from_table(self, table, sense=+1, devices=None):
         """The candidate-table variant the thesis driver uses (run.py:1234-1258): ``batch_size`` distinct rows of ``table`` by
-        repeated arg-best of the penalised acquisition."""
+        repeated arg-best of the penalised acquisition; ``devices``: scored on several GPUs from this one process."""
         lp = self.acquisition
         lp.update_batches(None, None, None)
-        rows = [lp.argbest(table, sense)[0]]
+        rows = [lp.argbest(table, sense, devices=devices)[0]]
         if self.batch_size >= 2:
             lipschitz, best_seen = self._constants()
             while len(rows) < self.batch_size:
                 lp.update_batches(np.atleast_2d(table[rows]), lipschitz, best_seen)
-                rows.append(lp.argbest(table, sense, exclude=rows)[0])
+                rows.append(lp.argbest(table, sense, exclude=rows, devices=devices)[0])
         lp.update_batches(None, None, None)
         return rows

@@ -227,6 +227,9 @@ static int merge_best(const std::vector<double> &v, const std::vector<int64_t> &
     return 0;
 }
 
+static int exchange_and_merge_best(gp_group *grp, std::vector<double> &v, std::vector<int64_t> &ix, int sense, int64_t *idx,
+                                   double *val);
+
 extern "C" int gp_group_acq_argbest(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int sense,
                          int64_t *idx, double *val) {
     if (!grp || !idx || !val) return fail(GP_ERR_ARG, "null argument");
@@ -235,8 +238,6 @@ extern "C" int gp_group_acq_argbest(gp_group_t *grp, int type, double par, doubl
     const int n = (int)grp->m.size();
     std::vector<double> v(n, sense > 0 ? -INFINITY : INFINITY);
     std::vector<int64_t> ix(n, -1);
-    std::vector<double> gv((size_t)n * n);       // what each member's all-gather returned
-    std::vector<int64_t> gi((size_t)n * n);
     int rc = for_members(grp, [&](int i) {
         if (grp->hi[i] == grp->lo[i]) return 0;
         int64_t li = -1;
@@ -245,9 +246,19 @@ extern "C" int gp_group_acq_argbest(gp_group_t *grp, int type, double par, doubl
         return r;
     });
     if (rc) return rc;
-    // (the collective starts only once EVERY member has its pair: a member that failed above would leave the others waiting)
+    return exchange_and_merge_best(grp, v, ix, sense, idx, val);
+}
+
+// Shared tail of the arg-best entry points: every member has its (value, global row) pair -- exchange (RCCL when the members hold
+// communicators) and merge.
+static int exchange_and_merge_best(gp_group *grp, std::vector<double> &v, std::vector<int64_t> &ix, int sense, int64_t *idx,
+                                   double *val) {
+    const int n = (int)grp->m.size();
     if (grp->rccl) {
-        rc = for_members(grp, [&](int i) {
+        std::vector<double> gv((size_t)n * n);
+        std::vector<int64_t> gi((size_t)n * n);
+        // (the collective starts only once EVERY member has its pair: a member that failed would leave the others waiting)
+        int rc = for_members(grp, [&](int i) {
             return gp_comm_allgather_best(grp->m[i], v[i], ix[i], &gv[(size_t)i * n], &gi[(size_t)i * n]);
         });
         if (rc) return rc;
@@ -259,6 +270,37 @@ extern "C" int gp_group_acq_argbest(gp_group_t *grp, int type, double par, doubl
         ix.assign(gi.begin(), gi.begin() + n);
     }
     return merge_best(v, ix, sense, idx, val);
+}
+
+// The local-penalisation acquisition over the whole table (run.py:1238-1257: penalised scores of the candidate table, arg-max,
+// rows already taken masked): every member scores its block with gp_acq_lp_argbest, the excluded GLOBAL rows handed to the member
+// whose block holds them.
+extern "C" int gp_group_acq_lp_argbest(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int transform,
+                            const double *Xb, int nb, const double *r_x0, const double *s_x0, int sense, const int64_t *exclude,
+                            int nex, int64_t *idx, double *val) {
+    if (!grp || !idx || !val || (nex > 0 && !exclude)) return fail(GP_ERR_ARG, "null argument");
+    if (grp->M < 1) return fail(GP_ERR_STATE, "gp_group_set_candidates first");
+    if (sense != 1 && sense != -1) return fail(GP_ERR_ARG, "sense must be +1 or -1");
+    if (nex < 0 || nex > 256) return fail(GP_ERR_ARG, "too many excluded rows (<= 256)");
+    for (int e = 0; e < nex; ++e)
+        if (exclude[e] < 0 || exclude[e] >= grp->M) return fail(GP_ERR_ARG, "excluded row out of range");
+    const int n = (int)grp->m.size();
+    std::vector<double> v(n, sense > 0 ? -INFINITY : INFINITY);
+    std::vector<int64_t> ix(n, -1);
+    int rc = for_members(grp, [&](int i) {
+        if (grp->hi[i] == grp->lo[i]) return 0;
+        std::vector<int64_t> mine;
+        for (int e = 0; e < nex; ++e)
+            if (exclude[e] >= grp->lo[i] && exclude[e] < grp->hi[i]) mine.push_back(exclude[e] - grp->lo[i]);
+        if ((long)mine.size() == grp->hi[i] - grp->lo[i]) return 0;   // every row of this block is taken already
+        int64_t li = -1;
+        int r = gp_acq_lp_argbest(grp->m[i], type, par, fmin, y_mean, y_std, transform, Xb, nb, r_x0, s_x0, sense, mine.data(),
+                                  (int)mine.size(), &li, &v[i]);
+        if (r == 0) ix[i] = grp->lo[i] + li;
+        return r;
+    });
+    if (rc) return rc;
+    return exchange_and_merge_best(grp, v, ix, sense, idx, val);
 }
 
 extern "C" int gp_group_acq_topk(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int sense, int k,

@@ -264,6 +264,11 @@ int gp_group_set_candidates(gp_group_t *grp, const double *Xs, int64_t M);
 /* gp_acq_argbest / gp_acq_topk over the whole table: idx are rows of the table passed to gp_group_set_candidates */
 int gp_group_acq_argbest(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int sense,
                          int64_t *idx, double *val);
+/* gp_acq_lp_argbest over the whole table (the local-penalisation batch loop of run.py:1238-1257): exclude[] holds rows of the
+ * table passed to gp_group_set_candidates */
+int gp_group_acq_lp_argbest(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int transform,
+                            const double *Xb, int nb, const double *r_x0, const double *s_x0, int sense,
+                            const int64_t *exclude, int nex, int64_t *idx, double *val);
 int gp_group_acq_topk(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int sense, int k,
                       int64_t *idx, double *val);
 

@@ -322,3 +322,27 @@ def test_small_m_path_equals_the_tile_path(N, D):
     h.predict(True)
     assert "cand_solve_rows" in [p["name"] for p in h.phases()]
     h.close()
+
+
+def test_local_penalization_batch_over_a_device_group():
+    """run.py:1238-1257 (LP-penalised scores of the candidate table, arg-max, rows already taken masked) through a device
+    group: `LocalPenalization.compute_batch_from_table(table, devices=[0, 0])` picks the rows the single-context loop picks --
+    the excluded rows are global rows of the table and reach the member whose block holds them."""
+    np.random.seed(4)
+    X, Y, table = O.synthetic_problem(150, 2, 3001, seed=14)
+    gm = gpo.GPModel(kernel=gpo.kern.Matern52(2, 1.0, 0.3), noise_var=0.01, max_iters=0, verbose=False)
+    gm.updateModel(X, Y, None, None)
+    space = gpo.Design_space([{'name': 'x', 'type': 'continuous', 'domain': (0, 1), 'dimensionality': 2}])
+    lp = gpo.AcquisitionLP(gm, space, None, gpo.AcquisitionEI(gm, space))
+    np.random.seed(9)
+    single = gpo.LocalPenalization(lp, 5).compute_batch_from_table(table, sense=+1)
+    np.random.seed(9)                                  # estimate_L draws its sample points from numpy's global generator
+    grouped = gpo.LocalPenalization(lp, 5).compute_batch_from_table(table, sense=+1, devices=[0, 0])
+    assert grouped == single and len(set(single)) == 5
+    # a penalised arg-best with exclusions straddling both blocks, and every row of one block taken
+    lp.update_batches(table[[10, 2500]], 3.0, float(Y.min()))
+    taken = [int(i) for i in (0, 1499, 1500, 1501, 3000)]
+    assert lp.argbest(table, +1, exclude=taken, devices=[0, 0]) == lp.argbest(table, +1, exclude=taken)
+    small = table[:4]
+    assert lp.argbest(small, +1, exclude=[0, 1], devices=[0, 0]) == lp.argbest(small, +1, exclude=[0, 1])
+    gm.model.close()

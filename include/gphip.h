@@ -324,6 +324,15 @@ int gp_synchronize(gp_t *gp);
  *                        true fp64 (NaNs propagate as in the reference).  "rns_group" / "rns_group_fit" (default 8, 1..16): panels per residue launch of the
  *                        candidate solve / of the trailing update; "rns_interleave" (default 1, process-wide): the eight
  *                        XCDs work on one modulus at a time.  Results do not depend on these three.
+ *   "inner_tiles"        tile columns per step of the in-panel factorisation: 1 (default) = diagonal tile, panel solve, K = 128 update;
+ *                        2 = a 256 x 256 diagonal block per launch (potrf_pair_kernel), both tile columns of the rows below per launch
+ *                        (trsm2_kernel), one K = 256 update -- half the dependent launches, the same wall time;
+ *                        "inner_min_rows": two columns only while at least this many row tiles lie below (default 0)
+ *   "small_m"            up to this many candidates (default 8, 0 = never) are solved as matrix-vector work bound by one read of L
+ *                        (csrc/smallm.hip: the acquisition optimiser's one-row calls) instead of through the 128-row tile path;
+ *                        gp_predict_full_cov / gp_posterior_samples always take the tile path
+ *   "debug_potrf_lds"    test hook, process-wide: extra dynamic LDS requested with every diagonal-tile launch (a refused launch beyond
+ *                        ~9 KB: what the launch checks are tested with)
  *   "profile_min_tiles"  see gp_profile
  * The number of CUs kept free of the trailing update for the look-ahead chain is fixed per process
  * (environment GPHIP_RESERVE_CUS, default 32; "reserve_cus" only checks the value). */

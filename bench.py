@@ -430,6 +430,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (starts its own ranks) or "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
+    if world > 1:
+        # A rank stuck inside a collective (a peer that never arrives, an RCCL bootstrap that finds no route) cannot be reached by a
+        # Python-level handler while it sits in C: the default action of SIGALRM ends the process, whatever launched it.
+        signal.signal(signal.SIGALRM, signal.SIG_DFL)
+        signal.alarm(int(os.environ.get("GPHIP_BENCH_RANK_TIMEOUT", "1500")))
     rdv = Rendezvous(rank, world) if world > 1 else None   # control channel between the ranks (no torch in any rank)
 
     from gaussian_process_optimization_amd import _lib
@@ -726,6 +731,7 @@ def main():
     if rdv is not None:
         rdv.barrier()
         rdv.close()
+        signal.alarm(0)
     h.close()
     if not ranks_agree:
         sys.stderr.write("rank %d: the ranks disagree on the winner: %s\n" % (rank, rank_records))

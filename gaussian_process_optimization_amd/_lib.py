@@ -95,6 +95,8 @@ SIGNATURES = [
                                                ctypes.c_int, c_int64_p, ctypes.c_int, c_int64_p, c_double_p]),
     ("gp_group_acq_topk", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, c_int64_p, c_double_p]),
+    ("gp_merge_best", ctypes.c_int, [ctypes.c_int, c_double_p, c_int64_p, ctypes.c_int, c_int64_p, c_double_p]),
+    ("gp_merge_topk", ctypes.c_int, [ctypes.c_int, c_double_p, c_int64_p, ctypes.c_int, ctypes.c_int, c_int64_p, c_double_p]),
     ("gp_last_phases", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), c_double_p, c_double_p,
                                       c_double_p]),
     ("gp_profile", ctypes.c_int, [_vp, ctypes.c_int]),

@@ -303,6 +303,22 @@ extern "C" int gp_group_acq_lp_argbest(gp_group_t *grp, int type, double par, do
     return exchange_and_merge_best(grp, v, ix, sense, idx, val);
 }
 
+// ---- the merges as host-only entry points (no device, no group): what every layout applies to the gathered pairs -------------
+extern "C" int gp_merge_best(int n, const double *vals, const int64_t *idxs, int sense, int64_t *idx, double *val) {
+    if (n < 1 || !vals || !idxs || !idx || !val) return fail(GP_ERR_ARG, "bad argument");
+    if (sense != 1 && sense != -1) return fail(GP_ERR_ARG, "sense must be +1 or -1");
+    return merge_best(std::vector<double>(vals, vals + n), std::vector<int64_t>(idxs, idxs + n), sense, idx, val);
+}
+
+static void merge_topk(const std::vector<double> &v, const std::vector<int64_t> &ix, int sense, int k, int64_t *idx, double *val);
+
+extern "C" int gp_merge_topk(int n, const double *vals, const int64_t *idxs, int sense, int k, int64_t *idx, double *val) {
+    if (n < 1 || k < 1 || !vals || !idxs || !idx || !val) return fail(GP_ERR_ARG, "bad argument");
+    if (sense != 1 && sense != -1) return fail(GP_ERR_ARG, "sense must be +1 or -1");
+    merge_topk(std::vector<double>(vals, vals + n), std::vector<int64_t>(idxs, idxs + n), sense, k, idx, val);
+    return 0;
+}
+
 extern "C" int gp_group_acq_topk(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int sense, int k,
                       int64_t *idx, double *val) {
     if (!grp || !idx || !val) return fail(GP_ERR_ARG, "null argument");
@@ -334,7 +350,14 @@ extern "C" int gp_group_acq_topk(gp_group_t *grp, int type, double par, double f
         v.assign(gv.begin(), gv.begin() + (size_t)n * k);
         ix.assign(gi.begin(), gi.begin() + (size_t)n * k);
     }
-    // k rounds of the lowest-index arg-best over the n k gathered pairs: a stable sort by (value, global row)
+    merge_topk(v, ix, sense, k, idx, val);
+    return 0;
+}
+
+// k rounds of the lowest-index arg-best over the gathered pairs: a stable sort by (value, global row); pairs with idx < 0 are
+// empty slots, a tail that cannot be filled is idx = -1
+static void merge_topk(const std::vector<double> &v, const std::vector<int64_t> &ix, int sense, int k, int64_t *idx, double *val) {
+    const double empty = sense > 0 ? -INFINITY : INFINITY;
     std::vector<char> used(v.size(), 0);
     for (int j = 0; j < k; ++j) {
         long best = -1;
@@ -351,5 +374,4 @@ extern "C" int gp_group_acq_topk(gp_group_t *grp, int type, double par, double f
             val[j] = v[best];
         }
     }
-    return 0;
 }

@@ -272,6 +272,12 @@ int gp_group_acq_lp_argbest(gp_group_t *grp, int type, double par, double fmin, 
 int gp_group_acq_topk(gp_group_t *grp, int type, double par, double fmin, double y_mean, double y_std, int sense, int k,
                       int64_t *idx, double *val);
 
+/* The merge every layout applies to gathered (value, global row) pairs, as host-only helpers (no device needed): the best pair /
+ * the k best in order, equal values lowest row first (np.argmax / np.argmin / a stable argsort on the unsharded vector); pairs with
+ * idx < 0 are empty slots; a top-k tail that cannot be filled is idx = -1. */
+int gp_merge_best(int n, const double *vals, const int64_t *idxs, int sense, int64_t *idx, double *val);
+int gp_merge_topk(int n, const double *vals, const int64_t *idxs, int sense, int k, int64_t *idx, double *val);
+
 /* ---- measurement ---------------------------------------------------------
  * Phase timings of the last gp_fit / gp_predict measured with HIP events on the
  * library's stream; names[i] is a static string, ms[i] milliseconds, flops[i] the

@@ -147,3 +147,34 @@ def test_launcher_deadline_and_signal_forwarding(tmp_path):
         except ProcessLookupError:
             alive = False
         assert not alive
+
+
+def test_rendezvous_under_torch_distributed_run(tmp_path):
+    """The driver starts the N > 1 bench as `python -m torch.distributed.run --nproc-per-node N ... bench.py`: the agent owns
+    MASTER_PORT (its own store listens there), the ranks are its children.  bench.Rendezvous must find its peers in exactly that
+    set-up -- socket file keyed by MASTER_PORT and the parent's PID -- and the ranks still import no torch themselves."""
+    import socket
+    child = tmp_path / "rdv_child.py"
+    child.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        import bench
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        rdv = bench.Rendezvous(rank, world, timeout_s=60)
+        uid = rdv.bcast(b"u" * 128 if rank == 0 else None)
+        recs = rdv.allgather((rank, os.getppid()))
+        rdv.barrier()
+        rdv.close()
+        open(os.path.join(%r, "t%%d.json" %% rank), "w").write(json.dumps(
+            {"uid": uid == b"u" * 128, "recs": recs, "torch": "torch" in sys.modules, "port": os.environ["MASTER_PORT"]}))
+    """ % (ROOT, str(tmp_path))))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), str(child)], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.load(open(tmp_path / ("t%d.json" % r))) for r in range(2)]
+    for r in recs:
+        assert r["uid"] and r["torch"] is False and r["port"] == str(port)
+        assert [x[0] for x in r["recs"]] == [0, 1] and r["recs"][0][1] == r["recs"][1][1]   # one parent: the agent

@@ -206,3 +206,43 @@ def test_bcast_fit_receiver_side_record():
     assert fitted == 1
     assert [fmin_valid, wi_valid, invp_valid, lr_valid, predicted] == [0, 0, 0, 0, 0]
     assert lib.gp_comm_selftest_fit_record(None, _lib.dptr(state), flags) == _lib.GP_ERR_ARG
+
+
+def test_group_merges_follow_numpy_tie_rules():
+    """gp_merge_best / gp_merge_topk (api_group.hip: what gp_group_* applies to the gathered (value, global row) pairs, host only)
+    against sharded.merge_best / merge_topk and against NumPy on the unsharded vector: lowest row among equal values, empty slots
+    (idx < 0) ignored, a top-k tail that cannot be filled marked -1."""
+    import ctypes
+    from gaussian_process_optimization_amd import _lib
+    from gaussian_process_optimization_amd.sharded import merge_best, merge_topk, shard_bounds
+    lib = _lib.load_library()
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        M = int(rng.integers(1, 60)); n = int(rng.integers(1, 7)); k = int(rng.integers(1, 8)); sense = int(rng.choice([-1, 1]))
+        scores = rng.integers(0, 6, M).astype(float)          # many ties
+        vals, idxs, kv, ki = [], [], [], []
+        for r in range(n):
+            lo, hi = shard_bounds(M, r, n)
+            blk = scores[lo:hi]
+            if hi > lo:
+                j = int(np.argmin(blk) if sense < 0 else np.argmax(blk))
+                vals.append(blk[j]); idxs.append(lo + j)
+                order = np.argsort(blk if sense < 0 else -blk, kind="stable")[:k]
+            else:
+                vals.append(np.inf if sense < 0 else -np.inf); idxs.append(-1)
+                order = np.zeros(0, dtype=int)
+            kv += list(blk[order]) + [np.inf if sense < 0 else -np.inf] * (k - order.size)
+            ki += list(lo + order) + [-1] * (k - order.size)
+        v = np.array(vals); ix = np.array(idxs, dtype=np.int64)
+        oi, ov = ctypes.c_int64(), ctypes.c_double()
+        assert lib.gp_merge_best(n, _lib.dptr(v), ix.ctypes.data_as(_lib.c_int64_p), sense, ctypes.byref(oi), ctypes.byref(ov)) == 0
+        ref = int(np.argmin(scores) if sense < 0 else np.argmax(scores))
+        assert (oi.value, ov.value) == (ref, scores[ref]) == merge_best(v, ix, sense)
+        kv = np.array(kv); ki = np.array(ki, dtype=np.int64)
+        ti = np.empty(k, dtype=np.int64); tv = np.empty(k)
+        assert lib.gp_merge_topk(n * k, _lib.dptr(kv), ki.ctypes.data_as(_lib.c_int64_p), sense, k, ti.ctypes.data_as(_lib.c_int64_p), _lib.dptr(tv)) == 0
+        full = np.argsort(scores if sense < 0 else -scores, kind="stable")[:k]
+        assert list(ti[:full.size]) == list(full) and list(ti[full.size:]) == [-1] * (k - full.size)
+        pi, pv = merge_topk(kv, ki, k, sense)
+        assert list(pi) == list(full) and list(tv[:full.size]) == list(scores[full])
+    assert lib.gp_merge_best(0, None, None, 1, None, None) == _lib.GP_ERR_ARG

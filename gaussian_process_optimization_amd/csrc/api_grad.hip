@@ -105,7 +105,10 @@ int run_predict_grad(gp_ctx *g) {
         const long mc = std::min(mc_max, M - m0);
         const long mcpad = round_up(mc, GP_TILE);
         const int mt = (int)(mcpad / GP_TILE);
-        launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, N, Npad, g->kp);
+        if (M <= g->small_m)
+            launch_cross_k_rows(g->s, g->dT, Npad, g->dXs, (int)M, g->dX, N, Npad, g->kp);
+        else
+            launch_cross_k(g->s, g->dT, Npad, g->dXs + m0 * g->D, mc, mcpad, g->dX, N, Npad, g->kp);
         // beta = K(Xs, X) Ky^-1   (gp.py:451-452; Ky^-1 symmetric => rows of Wi serve as the B operand)
         if (M <= g->small_m)   // a handful of rows: row dots with Ky^-1, one read of it (smallm.hip)
             launch_small_wi_product(g->s, g->dWi, Npad, Npad, g->dT, Npad, (int)mc, g->dCov, Npad);

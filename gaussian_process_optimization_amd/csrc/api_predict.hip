@@ -34,7 +34,7 @@ int run_predict(gp_ctx *g, int include_noise, bool tiles_only) {
         // A handful of rows (the acquisition optimiser's one-row calls): the solve as matrix-vector work bound by ONE read of
         // L (smallm.hip) instead of ~45 dependent tile launches; always true fp64.
         int ph = phase_begin(g, "cross_k", 0.0, 8.0 * (double)(N + M) * g->D + 8.0 * (double)N * M);
-        launch_cross_k(g->s, g->dT, Npad, g->dXs, M, round_up(M, GP_TILE), g->dX, g->N, Npad, g->kp);
+        launch_cross_k_rows(g->s, g->dT, Npad, g->dXs, (int)M, g->dX, g->N, Npad, g->kp);
         phase_end(g, ph);
         ph = phase_begin(g, "cand_solve_rows", (double)N * N * M, 8.0 * (double)N * N / 2);
         launch_small_forward_solve(g->s, g->dA, Npad, g->dInvP, g->invp_W, Npad, g->dT, g->dT2, Npad, (int)M);

@@ -9,10 +9,12 @@
 // W dependent 128-column steps.  Built batched over all panels at once: the solve of the identity
 // against L_JJ (2W-1 small launches, each covering every panel) gives L_JJ^-T, then one transpose.
 int ensure_panel_inv(gp_ctx *g) {
-    if (g->invp_valid && g->invp_W == g->panel_tiles) return 0;
     const long Npad = g->Npad, lda = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
     const int W = std::min(g->panel_tiles, nt);
+    // (the width actually built is min(panel_tiles, nt): compared with panel_tiles itself, a matrix of fewer tiles than one
+    // panel -- N <= 640 by default, the size of most BO loops -- rebuilt its inverted panel on EVERY predict call: round 4 finding)
+    if (g->invp_valid && g->invp_W == W) return 0;
     const long PB = (long)W * GP_TILE;
     const int nJ = (nt + W - 1) / W, nF = nt / W, Wl = nt % W;
     int rc;

@@ -125,6 +125,10 @@ void launch_set_rhs(hipStream_t s, double *A, long lda, const double *Y, long N,
 void launch_cross_k(hipStream_t s, double *T, long ldt, const double *Xs, long M, long Mpad,
                     const double *X, long N, long Npad, const KernParams &kp);
 
+// the same for M <= 8 candidate rows only (rows 0 .. M-1 of T, columns 0 .. Npad-1; no padding rows): the small-M path
+void launch_cross_k_rows(hipStream_t s, double *T, long ldt, const double *Xs, int M, const double *X, long N, long Npad,
+                         const KernParams &kp);
+
 // logdet = 2 * sum_i log A[i*lda+i], i < N (deterministic single-block reduction)
 void launch_logdet(hipStream_t s, const double *A, long lda, long N, double *out);
 // out[p] = sum_i z_p[i]^2 for the RHS rows z_p = A[(Npad+p)*lda + i]

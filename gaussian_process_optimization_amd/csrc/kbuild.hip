@@ -239,3 +239,44 @@ void launch_cross_k(hipStream_t s, double *T, long ldt, const double *Xs, long M
     else
         GP_LAUNCH(cross_k_kernel<0>, grid, dim3(256), shm, s, T, ldt, Xs, M, X, N, kp, nti);
 }
+
+// ---- K(Xs, X) for a handful of candidate rows (the small-M path, smallm.hip): one training point per thread, every candidate ----
+// The tile kernel above computes 128 candidate rows per workgroup whatever M is (15 us for one row at N = 512); here the work is
+// M N covariance evaluations and nothing else.  Same arithmetic per entry as cross_k_kernel (inputs divided by the lengthscale, then
+// differences, squares summed in dimension order): the same bits.
+#define CKR_MAX_M 8
+__global__ __launch_bounds__(256) void cross_k_rows_kernel(double *T, long ldt, const double *Xs, int M, const double *X, long N,
+                                                           long Npad, KernParams kp) {
+    extern __shared__ double xs[];   // [M][D], divided by the lengthscale
+    const int D = kp.D;
+    for (int idx = threadIdx.x; idx < M * D; idx += 256) xs[idx] = Xs[idx] / kp_div(kp, idx % D);
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad) return;
+    double acc[CKR_MAX_M];
+#pragma unroll
+    for (int m = 0; m < CKR_MAX_M; ++m) acc[m] = kp.gower ? 1.0 : 0.0;
+    if (i < N) {
+        for (int d = 0; d < D; ++d) {
+            const double b = X[i * D + d] / kp_div(kp, d);
+#pragma unroll
+            for (int m = 0; m < CKR_MAX_M; ++m) {
+                if (m < M) {
+                    const double df = xs[m * D + d] - b;
+                    if (kp.gower) acc[m] *= gower_factor(kp.kernel, kp.variance, df, kp.gdisc[d]);
+                    else acc[m] = fma(df, df, acc[m]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < CKR_MAX_M; ++m)
+        if (m < M) T[(long)m * ldt + i] = (i < N) ? (kp.gower ? acc[m] : k_of_r2(kp.kernel, kp.variance, acc[m])) : 0.0;
+}
+
+void launch_cross_k_rows(hipStream_t s, double *T, long ldt, const double *Xs, int M, const double *X, long N, long Npad,
+                         const KernParams &kp) {
+    if (M < 1 || M > CKR_MAX_M) return;
+    GP_LAUNCH(cross_k_rows_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), (size_t)M * kp.D * sizeof(double), s, T, ldt, Xs, M,
+              X, N, Npad, kp);
+}

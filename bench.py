@@ -198,6 +198,21 @@ class Rendezvous(object):
             self.conn.close()
 
 
+def on_stderr(fn):
+    """Run fn() with file descriptor 1 pointing at stderr: librccl prints its version banner with printf when a communicator is
+    set up, and the job's stdout carries ONE JSON line.  The C-level buffer is flushed before the descriptor is put back."""
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return fn()
+    finally:
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def rccl_identity():
     """Which librccl this process has mapped (the first mapping of /proc/self/maps whose file name says rccl) -- libgphip is
     linked against /opt/rocm/lib/librccl.so.1; a python package that bundles its own copy could get in first."""
@@ -431,6 +446,7 @@ def main():
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
     if world > 1:
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL's log lines belong on stderr: stdout carries the ONE JSON line
         # A rank stuck inside a collective (a peer that never arrives, an RCCL bootstrap that finds no route) cannot be reached by a
         # Python-level handler while it sits in C: the default action of SIGALRM ends the process, whatever launched it.
         signal.signal(signal.SIGALRM, signal.SIG_DFL)
@@ -475,7 +491,7 @@ def main():
         ok, uid = 1, None
         if rank == 0:
             try:
-                uid = h.comm_unique_id()
+                uid = on_stderr(h.comm_unique_id)
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write("rank 0: RCCL unique id failed: %s\n" % e)
         uid = rdv.bcast(uid)
@@ -483,7 +499,7 @@ def main():
             ok = 0
         else:
             try:
-                h.comm_init(uid, rank, world)
+                on_stderr(lambda: h.comm_init(uid, rank, world))
                 rccl_ranks = h.comm_info()[1]
             except Exception as e:  # noqa: BLE001
                 ok = 0

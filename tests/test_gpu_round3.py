@@ -222,6 +222,7 @@ def test_bench_starts_its_own_ranks_on_one_device():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]
+    assert out.stdout.strip() == lines[0].strip()        # nothing else on stdout: librccl's banner is sent to stderr
     d = json.loads(lines[0])
     cfg = d["config"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"

@@ -279,6 +279,7 @@ extern "C" int gp_create(gp_t **out, int device) {
     if (const char *ev = getenv("GPHIP_EMULATE_FP64")) g->emulate_fp64 = atoi(ev) ? 1 : 0;
     if (const char *ev = getenv("GPHIP_INNER_TILES")) g->inner_tiles = atoi(ev) == 2 ? 2 : 1;
     if (const char *ev = getenv("GPHIP_INNER_MIN_ROWS")) g->inner_min_rows = std::max(0, atoi(ev));   // A/B of the in-panel step across unmodified tools
+    if (const char *ev = getenv("GPHIP_OWN_KEEP_PER_ROW")) g->own_keep_per_row = std::max(0, atoi(ev));
     *out = g;
     return 0;
 }
@@ -349,6 +350,12 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "inner_min_rows")) {
         if (value < 0) return fail(GP_ERR_ARG, "inner_min_rows < 0");
         g->inner_min_rows = (int)std::min<int64_t>(value, 1 << 20);
+    } else if (!strcmp(name, "own_keep_per_row")) {
+        if (value < 0) return fail(GP_ERR_ARG, "own_keep_per_row < 0");
+        g->own_keep_per_row = (int)std::min<int64_t>(value, 1 << 20);
+    } else if (!strcmp(name, "own_keep_base")) {
+        if (value < 0) return fail(GP_ERR_ARG, "own_keep_base < 0");
+        g->own_keep_base = (int)std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "lookahead")) {
         g->lookahead = value ? 1 : 0;
     } else if (!strcmp(name, "lookahead_min_tiles")) {

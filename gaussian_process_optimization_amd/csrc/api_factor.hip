@@ -131,6 +131,7 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
         if (pp.init) pp.init(g->s_pred);
     }
     int next_pred = 0;
+    int own_prev = nt;   // columns owned by the chain stream at the previous panel (the range never grows)
     // Only the first `pipe_stages` candidate stages ride behind the factorisation (on the CU-masked stream, released
     // at panel pred_start); the caller runs the rest on the main stream, on every CU, once the factor is complete.
     const int pstages = pp.on ? std::max(1, std::min(nJu, pp.stages)) : 0;
@@ -195,6 +196,24 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
             }
         }
         if (J1 >= nt) break;
+        // Columns owned by the chain stream (options own_keep_*): in the head of the factorisation the chain finishes panel J+1 long
+        // before bulk(J) has drained and would wait for it, with the CUs kept free of the bulk stream idle.  bulk(J) therefore keeps
+        // only what lasts as long as the chain is busy with the next panel (a count of tiles linear in the rows below it); the
+        // rest -- the last tile columns oc .. nt -- takes panel J's update on THIS stream, after chain(J), on every CU.  The owned
+        // range only shrinks with J, so own(J) never meets a tile bulk(J-1) writes, and a column handed back to the bulk stream
+        // had its last update here before chain(J+1), which bulk(J+1) waits for.  Same contraction per tile in the same order:
+        // the same bits as without.
+        int oc = nt;
+        if (!emu && g->own_keep_per_row > 0 && J2 < nt) {
+            const long n = nt - J2;
+            long t_own = n * (n + 1) / 2 + n - (g->own_keep_base + (long)g->own_keep_per_row * n);   // tiles right of J2 (with the rhs row) minus the kept ones
+            int c = 0;
+            while (c < own_prev && (long)(c + 1) * (c + 2) / 2 + (c + 1) <= t_own) ++c;
+            own_prev = c;
+            oc = nt - c;
+        }
+        if (oc < nt && J >= 1)
+            gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K, TileSet{0, R1, oc, nt, 1});
         // the look-ahead update is on the critical path: enqueue it before the trailing update so that its
         // workgroups reach the dispatcher first once bulk(J-1) has drained
         if (J >= 1) GP_NOTE(hipStreamWaitEvent(sp, la_event(g, EV_BULK, J - 1), 0));
@@ -202,6 +221,8 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
         // 0 .. J-1 -- on the bulk stream, before bulk(J-1) was recorded)
         gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
              TileSet{0, R1, J1, J2, 1});
+        if (oc < nt && J == 0)   // (the first panel has no bulk launch to wait for: the critical update goes first)
+            gemm(g, sp, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K, TileSet{0, R1, oc, nt, 1});
         if (J2 < nt) {
             GP_NOTE(hipStreamWaitEvent(sb, eF, 0));
             if (emu) {
@@ -268,8 +289,9 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
                     }
                 }
             } else {
-                gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
-                     TileSet{0, R1, J2, nt, 1});
+                if (J2 < oc)
+                    gemm(g, sb, 1, A, lda, A + (long)J0 * GP_TILE, lda, A + (long)J0 * GP_TILE, lda, 1, K,
+                         TileSet{0, R1, J2, oc, 1});
             }
             if (!bulk_recorded) GP_NOTE(hipEventRecord(la_event(g, EV_BULK, J), sb));
         }

@@ -124,6 +124,11 @@ struct gp_ctx {
     int panel_tiles = 6;
     int lookahead = 1;
     int inner_min_rows = 0;         // ... only while at least this many row tiles lie below the pair (below that the 128-column step's shorter launches win)
+    // look-ahead factorisation, columns owned by the chain stream (factor_lookahead): the bulk stream keeps own_keep_base + own_keep_per_row * n
+    // tiles of a trailing update with n row tiles below the look-ahead panel -- what lasts as long as the chain is busy with that panel --
+    // and the rest, the far columns, is updated on the chain stream once the panel is done (every CU).  own_keep_per_row = 0: off.
+    // Defaults from the sweep of round 4 (N = 8192 ... 32768, profiles/r04_own_columns.txt)
+    int own_keep_per_row = 36, own_keep_base = 200;
     int inner_tiles = 1;            // tile columns per step of the in-panel factorisation (2: potrf_pair_kernel + trsm2 + K = 256 update;
                                     // measured in round 4: the same wall time as 1 at every size, profiles/r04_pair_step_experiment.txt)
     int lookahead_min_tiles = 40;   // gp_fit: matrices of at most this many tiles (N <= 5120) take the single-stream factorisation

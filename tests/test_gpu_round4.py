@@ -281,6 +281,37 @@ def test_pair_step_factorisation_matches_the_tile_step(N):
     h.close()
 
 
+@pytest.mark.parametrize("N,keep", [(3000, 4), (6100, 10), (12416, 36)])
+def test_chain_owned_columns_leave_the_factor_bitwise_unchanged(N, keep):
+    """Look-ahead factorisation, options own_keep_per_row / own_keep_base (factor_lookahead): the last tile columns of the
+    trailing matrix take their panel updates on the chain stream instead of the bulk stream.  Every tile still sees the same
+    panels in the same order with the same K = 768 contraction, so factor, LML and posterior are BITWISE those of the plain
+    schedule (own_keep_per_row = 0) -- for gp_fit, gp_fit_predict and gp_fit_grad, with a ragged last panel, and again on a
+    refit.  N = 12416 is the default rule at a size where it owns columns (it owns none below ~90 tiles); the smaller cases
+    force a wide owned range so that hand-back of columns to the bulk stream happens at every panel."""
+    X, Y, Xs = O.synthetic_problem(N, 5, 700, seed=N)
+    h = _lib.Handle(0)
+    h.set_option("emulate_fp64", 0)
+    h.set_option("lookahead_min_tiles", 0)
+    h.set_data(X, Y)
+    h.set_params(0, 0, 1.2, [0.5], 1e-2)
+    h.set_candidates(Xs)
+    h.set_option("own_keep_per_row", 0)
+    lml0 = h.fit()[0]
+    L0 = h.chol()
+    (_, _, _), mu0, v0 = h.fit_predict(True)
+    g0 = h.fit_grad(1)
+    h.set_option("own_keep_per_row", keep)
+    h.set_option("own_keep_base", 0 if keep < 36 else 200)
+    for _ in range(2):
+        assert h.fit()[0] == lml0 and np.array_equal(h.chol(), L0)
+    (lml1, _, _), mu1, v1 = h.fit_predict(True)
+    assert lml1 == lml0 and np.array_equal(mu1, mu0) and np.array_equal(v1, v0)
+    g1 = h.fit_grad(1)
+    assert g1[0] == g0[0] and g1[1][0] == g0[1][0] and np.array_equal(g1[1][1], g0[1][1]) and g1[1][2] == g0[1][2]
+    h.close()
+
+
 @pytest.mark.parametrize("N,D", [(700, 3), (5000, 6)])
 def test_small_m_path_equals_the_tile_path(N, D):
     """Up to "small_m" (8) candidates take the matrix-vector solve of smallm.hip (forward substitution over the panels, row dots

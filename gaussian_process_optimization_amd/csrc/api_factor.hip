@@ -9,7 +9,7 @@
 // side_inv (the model's own factor only): the inverted diagonal panel of each panel is built on the side stream as soon as that
 // panel's columns are final, beside the trailing update and the next panel -- one event record per panel on this stream.
 // One step of the in-panel factorisation starting at tile column j of a panel that ends at J1; returns the next column.
-// Two columns at a time where the panel has them ("inner_tiles" 2, the default): the 256 x 256 diagonal block in ONE launch
+// Option "inner_tiles" 2 (default 1: measured neutral) takes two columns at a time: the 256 x 256 diagonal block in ONE launch
 // (potrf_pair_kernel: both diagonal tiles, the tile between them solved and the second one updated inside), ONE launch that
 // solves both tile columns of the rows below (trsm2.hip), ONE K = 256 update of the panel's remaining columns -- three
 // dependent launches per 256 columns where the 128-column step takes six, and contractions twice as long.

@@ -280,6 +280,7 @@ extern "C" int gp_create(gp_t **out, int device) {
     if (const char *ev = getenv("GPHIP_INNER_TILES")) g->inner_tiles = atoi(ev) == 2 ? 2 : 1;
     if (const char *ev = getenv("GPHIP_INNER_MIN_ROWS")) g->inner_min_rows = std::max(0, atoi(ev));   // A/B of the in-panel step across unmodified tools
     if (const char *ev = getenv("GPHIP_OWN_KEEP_PER_ROW")) g->own_keep_per_row = std::max(0, atoi(ev));
+    if (const char *ev = getenv("GPHIP_OWN_KEEP_BASE")) g->own_keep_base = std::max(0, atoi(ev));   // (a wide owned range forced on an unmodified test suite)
     *out = g;
     return 0;
 }

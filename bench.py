@@ -421,6 +421,10 @@ def main():
                     help="--gpus N without a launcher: stop the ranks and exit 124 after this many seconds")
     ap.add_argument("--no-c4-reference", action="store_true",
                     help="C4, N > 1: skip rank 0's un-timed single-GPU pass over the whole table (the strong-scaling base)")
+    ap.add_argument("--no-c4-section", action="store_true",
+                    help="N > 1, default workload: skip the second measurement (C4: ONE table of --c4-M candidates split over the ranks)")
+    ap.add_argument("--c4-M", type=int, default=1000000, help="N > 1, default workload: size of the C4 section's candidate table")
+    ap.add_argument("--c4-steps", type=int, default=3, help="timed iterations of the C4 section")
     args = ap.parse_args()
 
     if args.small_calls:
@@ -444,7 +448,13 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (starts its own ranks) or "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
-    workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
+    # Default workload at every N: the configuration the metric is quoted on (C3).  The fit does not shard (replicas only); the
+    # candidates do: on N > 1 ranks every rank scores its own 10^4 candidates of an N x 10^4 table and the ranks all-gather their
+    # arg-best over RCCL -- weak scaling, value = N x job iterations/s, so that the driver's N = 1, 2, 4, 8 series is ONE workload.
+    # BASELINE.json's candidate-sharding configuration (C4: one table of 10^6 candidates split over the ranks, strong scaling) is
+    # measured in the same run as a second object of the line (c4_sharded); `--workload c4` runs it as the line itself.
+    workload = args.workload if args.workload != "auto" else "c3"
+    with_c4 = args.workload == "auto" and world > 1 and not args.no_c4_section
     if world > 1:
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL's log lines belong on stderr: stdout carries the ONE JSON line
         # A rank stuck inside a collective (a peer that never arrives, an RCCL bootstrap that finds no route) cannot be reached by a
@@ -585,9 +595,8 @@ def main():
         # every rank merged the same gathered pairs: the winners must be identical (C4; C3 ranks score different tables)
         rank_records = rdv.allgather({"rank": rank, "best_row": int(out[1]), "best_value": float(out[2]),
                                       "lml": float(out[0])})
-        if workload == "c4":
-            ranks_agree = all(r["best_row"] == rank_records[0]["best_row"] and
-                              r["best_value"] == rank_records[0]["best_value"] for r in rank_records)
+        ranks_agree = all(r["best_row"] == rank_records[0]["best_row"] and
+                          r["best_value"] == rank_records[0]["best_value"] for r in rank_records)
 
     # second, clearly labelled measurement (NOT the headline): the same C3 step with the candidate solve's updates on the
     # int8 matrix cores in residue form (option "emulate_fp64", csrc/rns.hip; fp64-equivalent results, parity-tested in
@@ -649,6 +658,57 @@ def main():
     cs = h.gemm_stats()
     h.profile(False)
 
+    # N > 1, default workload: the candidate-sharding configuration in the same run (see above).  ONE table for the whole job
+    # (seed 1236), this rank's contiguous block of it; rank 0 first times one pass over the WHOLE table on its own GPU (the
+    # single-GPU base the sharded rate is read against) while the others wait at the barrier.
+    c4_sec = None
+    if with_c4:
+        M4 = args.c4_M
+        lo4, hi4 = shard_bounds(M4, rank, world)
+        table = np.random.default_rng(1236).uniform(0, 1, (M4, D))
+        h.set_params(_lib.GP_KERNEL_MATERN52, 0, 1.0, [0.25 * np.sqrt(D)], 1e-2)
+
+        def c4_iter(first_row):
+            lml4 = h.fit()[0]
+            i4, v4 = h.acq_argbest(_lib.GP_ACQ_EI, 0.01, h.fmin(), -1)
+            return (lml4,) + tuple(exchange(v4, first_row + i4))
+        ref4 = None
+        if rank == 0 and not args.no_c4_reference:
+            h.set_candidates(table)
+            h.fit(); h.acq_argbest(_lib.GP_ACQ_EI, 0.01, h.fmin(), -1)     # warm-up (allocations)
+            h.synchronize()
+            t4 = time.perf_counter()
+            h.fit()
+            i1, v1 = h.acq_argbest(_lib.GP_ACQ_EI, 0.01, h.fmin(), -1)
+            h.synchronize()
+            ref4 = {"single_gpu_iter_s": time.perf_counter() - t4, "best_row": int(i1), "best_value": v1}
+        h.set_candidates(table[lo4:hi4].copy())
+        del table
+        barrier()
+        out4 = c4_iter(lo4)                                                  # warm-up
+        barrier()
+        t4 = time.perf_counter()
+        for _ in range(args.c4_steps):
+            out4 = c4_iter(lo4)
+        barrier()
+        el4 = max_over_ranks(time.perf_counter() - t4)
+        recs4 = rdv.allgather({"rank": rank, "best_row": int(out4[1]), "best_value": float(out4[2])})
+        agree4 = all(r["best_row"] == recs4[0]["best_row"] and r["best_value"] == recs4[0]["best_value"] for r in recs4)
+        ranks_agree = ranks_agree and agree4
+        h.fit()
+        fit4 = sum(ph_["ms"] for ph_ in h.phases())
+        ms4 = el4 / args.c4_steps * 1e3
+        c4_sec = {"workload": "C4 (BASELINE.json configs[3]): N=%d, D=%d Matern-5/2 iso, fit (replicated per rank) + posterior + EI over "
+                              "ONE table of %d candidates split over %d ranks + device arg-best + RCCL all-gather of (best, row) + "
+                              "lowest-index merge" % (N, D, M4, world),
+                  "scaling": "strong", "candidates_total": M4, "candidates_this_rank": hi4 - lo4, "steps": args.c4_steps,
+                  "ms_per_iter": ms4, "iters_per_s": 1e3 / ms4, "collective": collective,
+                  "fit_ms_per_iter_not_scaling": round(fit4, 3), "predict_ei_ms_per_iter_this_rank": round(ms4 - fit4, 3),
+                  "single_gpu_reference": ref4,
+                  "speedup_vs_single_gpu": None if not ref4 else ref4["single_gpu_iter_s"] * 1e3 / ms4,
+                  "best_row_matches_single_gpu": None if not ref4 else bool(ref4["best_row"] == int(out4[1])),
+                  "ranks_agree_on_winner": agree4, "best_candidate_global_row": int(out4[1]), "best_value": float(out4[2])}
+
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -662,8 +722,11 @@ def main():
                    "candidates_per_gpu": M, "entry_point": "gp_fit_predict" if fused else "gp_fit + gp_predict"}
             scaling, value = "weak", world * job_rate
             if world > 1:
-                cfg["note_n_gpus"] = ("C3 on N > 1 ranks replicates the fit and gives every rank its own 10^4 candidates: "
-                                      "value counts N replicas and says nothing about scaling; the scaling workload is C4")
+                cfg["note_n_gpus"] = ("the fit does not shard (replicas only, SURVEY.md 8e): every rank refits the same model and "
+                                      "scores its own %d candidates of an N x %d table, the ranks all-gather their arg-best; value "
+                                      "= N x job iterations/s (weak scaling: per-GPU work fixed).  The candidate-SHARDING "
+                                      "configuration (C4, one table split over the ranks, strong scaling) is measured in the same "
+                                      "run: c4_sharded" % (M, M))
         else:
             cfg = {"workload": "C4 (BASELINE.json configs[3]): N=%d, D=%d Matern-5/2 iso, fit (replicated per rank) + posterior "
                                "+ EI over ONE table of %d candidates split over %d rank(s) + device arg-best + RCCL "
@@ -740,6 +803,8 @@ def main():
         }
         if emulated is not None:
             result["emulated_fp64_second_line"] = emulated
+        if c4_sec is not None:
+            result["c4_sharded"] = c4_sec
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(N, D, 10000, sample_only=args.cpu_baseline_sample)
         print(json.dumps(result))

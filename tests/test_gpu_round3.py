@@ -204,12 +204,13 @@ def test_optimize_on_a_flat_ridge_ends_at_the_same_likelihood(monkeypatch, mode,
 
 
 def test_bench_starts_its_own_ranks_on_one_device():
-    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command): the parent spawns two
-    fresh rank processes, they rendezvous over 127.0.0.1, shard ONE candidate table (C4, reduced: N = 2048, 20 000 candidates),
-    exchange (best value, global row) pairs and print ONE JSON line from rank 0.  Both ranks sit on device 0 here
-    (GPHIP_BENCH_SAME_DEVICE: a one-GPU box), where RCCL refuses the duplicate device and the pairs travel over the ranks' control
-    channel (labelled so); on an
-    8-GPU node the only difference is the device index."""
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command): the parent spawns two fresh rank
+    processes, they rendezvous over 127.0.0.1 and print ONE JSON line from rank 0 that holds BOTH multi-rank measurements (reduced
+    here: N = 2048): the metric's own workload with every rank scoring its own candidates and an arg-best exchange per step
+    (weak scaling: the series the driver's N = 1, 2, 4, 8 runs form), and the candidate-sharding configuration C4 -- ONE table of
+    20 000 candidates split over the ranks, winner compared with rank 0's single-GPU pass over the whole table.  Both ranks sit on
+    device 0 here (GPHIP_BENCH_SAME_DEVICE: a one-GPU box), where RCCL refuses the duplicate device and the pairs travel over the
+    ranks' control channel (labelled so); on an 8-GPU node the only difference is the device index."""
     import json
     import os
     import subprocess
@@ -217,7 +218,7 @@ def test_bench_starts_its_own_ranks_on_one_device():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPHIP_EMULATE_FP64")}
     env["GPHIP_BENCH_SAME_DEVICE"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--N", "2048", "--M", "20000",
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--N", "2048", "--M", "3000", "--c4-M", "20000",
                           "--steps", "2", "--warmup", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -225,13 +226,19 @@ def test_bench_starts_its_own_ranks_on_one_device():
     assert out.stdout.strip() == lines[0].strip()        # nothing else on stdout: librccl's banner is sent to stderr
     d = json.loads(lines[0])
     cfg = d["config"]
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["metric"].startswith("GP fit+predict iters/sec") and cfg["workload"].startswith("C3")
+    assert cfg["candidates_per_gpu"] == 3000 and abs(d["value"] - 2 * cfg["job_iters_per_s"]) < 1e-9 * d["value"]
     assert "launch_ranks" in cfg["launcher"]
     assert cfg["ranks_agree_on_winner"] is True
-    assert cfg["best_row_matches_single_gpu"] is True
-    assert cfg["candidates_total"] == 20000 and cfg["candidates_this_rank"] == 10000
     assert {r["rank"] for r in cfg["rank_records"]} == {0, 1}
+    assert 0 <= cfg["best_candidate_global_row"] < 6000                       # a row of the 2 x 3000 table
     assert cfg["collective"].startswith("host sockets") or cfg["rccl_comm_ranks"] == 2
+    c4 = d["c4_sharded"]
+    assert c4["scaling"] == "strong" and c4["workload"].startswith("C4")
+    assert c4["candidates_total"] == 20000 and c4["candidates_this_rank"] == 10000
+    assert c4["ranks_agree_on_winner"] is True and c4["best_row_matches_single_gpu"] is True
+    assert c4["speedup_vs_single_gpu"] > 0 and c4["ms_per_iter"] > 0
     # no rank imported torch; the line says which librccl the process mapped and what version it reports
     assert cfg["torch_imported"] is False
     assert cfg["rccl"]["version"] > 20000 and any("rccl" in p for p in cfg["rccl"]["librccl_mapped"])

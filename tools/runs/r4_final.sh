@@ -35,7 +35,7 @@ if [ "$what" = prof ] || [ "$what" = all ]; then
   done
   timeout -k 10 300 python3 tools/configs_timing.py > $out/configs.txt 2>&1; cat $out/configs.txt
   timeout -k 10 200 python3 tools/emul_fit_timing.py > $out/emul.txt 2>&1; grep "^emulate" $out/emul.txt | cut -c1-180
-  GPHIP_BENCH_SAME_DEVICE=1 timeout -k 10 300 python3 bench.py --gpus 2 --M 200000 --steps 2 2> $out/bench2.err | grep '^{"metric"' > $out/bench2.json; echo "bench --gpus 2 (same device) rc=$?"
+  GPHIP_BENCH_SAME_DEVICE=1 timeout -k 10 300 python3 bench.py --gpus 2 --c4-M 200000 --steps 2 2> $out/bench2.err | grep '^{"metric"' > $out/bench2.json; echo "bench --gpus 2 (same device) rc=$?"
   python3 - <<PY
 import json
 d=json.load(open("$out/bench.json"))

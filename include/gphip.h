@@ -335,7 +335,7 @@ int gp_synchronize(gp_t *gp);
  *                        (trsm2_kernel), one K = 256 update -- half the dependent launches, the same wall time;
  *                        "inner_min_rows": two columns only while at least this many row tiles lie below (default 0)
  *   "own_keep_per_row"   look-ahead factorisation: of a trailing update with n row tiles below the look-ahead panel the masked bulk stream keeps
- *   "own_keep_base"      own_keep_base + own_keep_per_row * n tiles (what lasts as long as the chain is busy with that panel; defaults 200 and
+ *   "own_keep_base"      own_keep_base + own_keep_per_row * n * panel_tiles / 6 tiles (what lasts as long as the chain is busy with that panel; defaults 200 and
  *                        36); the rest, the far tile columns, is updated on the chain stream -- every CU -- in the window in which the chain
  *                        would wait for the bulk stream.  Same bits as without; own_keep_per_row = 0 switches it off
  *   "small_m"            up to this many candidates (default 8, 0 = never) are solved as matrix-vector work bound by one read of L

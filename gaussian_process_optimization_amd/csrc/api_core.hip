@@ -354,6 +354,9 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "own_keep_per_row")) {
         if (value < 0) return fail(GP_ERR_ARG, "own_keep_per_row < 0");
         g->own_keep_per_row = (int)std::min<int64_t>(value, 1 << 20);
+    } else if (!strcmp(name, "own_keep_pipe_pct")) {
+        if (value < 0 || value > 400) return fail(GP_ERR_ARG, "own_keep_pipe_pct out of range");
+        g->own_keep_pipe_pct = (int)value;
     } else if (!strcmp(name, "own_keep_base")) {
         if (value < 0) return fail(GP_ERR_ARG, "own_keep_base < 0");
         g->own_keep_base = (int)std::min<int64_t>(value, 1 << 20);

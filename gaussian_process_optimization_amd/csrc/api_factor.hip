@@ -207,7 +207,11 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
         if (!emu && g->own_keep_per_row > 0 && J2 < nt) {
             const long n = nt - J2;
             // tiles right of J2 (with the rhs row) minus the kept ones (the chain's time per panel grows with the panel width: per_row is per 6 tiles)
-            long t_own = n * (n + 1) / 2 + n - (g->own_keep_base + (long)g->own_keep_per_row * n * W / 6);
+            long keep = g->own_keep_base + (long)g->own_keep_per_row * n * W / 6;
+            // (one-call entry points: once the candidate stages share the bulk stream's CUs the trailing update lasts longer and the
+            // chain waits again; the bulk stream then keeps own_keep_pipe_pct % of the rule's share)
+            if (pp.on && J >= pred_start) keep = keep * g->own_keep_pipe_pct / 100;
+            long t_own = n * (n + 1) / 2 + n - keep;
             int c = 0;
             while (c < own_prev && (long)(c + 1) * (c + 2) / 2 + (c + 1) <= t_own) ++c;
             own_prev = c;

@@ -129,6 +129,7 @@ struct gp_ctx {
     // and the rest, the far columns, is updated on the chain stream once the panel is done (every CU).  own_keep_per_row = 0: off.
     // Defaults from the sweep of round 4 (N = 8192 ... 32768, profiles/r04_own_columns.txt)
     int own_keep_per_row = 36, own_keep_base = 200;
+    int own_keep_pipe_pct = 0;      // ... scaled by this while pipelined candidate stages share the bulk stream's CUs (0: the owned range stops shrinking there; fused step -0.3 ms)
     int inner_tiles = 1;            // tile columns per step of the in-panel factorisation (2: potrf_pair_kernel + trsm2 + K = 256 update;
                                     // measured in round 4: the same wall time as 1 at every size, profiles/r04_pair_step_experiment.txt)
     int lookahead_min_tiles = 40;   // gp_fit: matrices of at most this many tiles (N <= 5120) take the single-stream factorisation

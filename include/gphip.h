@@ -337,7 +337,9 @@ int gp_synchronize(gp_t *gp);
  *   "own_keep_per_row"   look-ahead factorisation: of a trailing update with n row tiles below the look-ahead panel the masked bulk stream keeps
  *   "own_keep_base"      own_keep_base + own_keep_per_row * n * panel_tiles / 6 tiles (what lasts as long as the chain is busy with that panel; defaults 200 and
  *                        36); the rest, the far tile columns, is updated on the chain stream -- every CU -- in the window in which the chain
- *                        would wait for the bulk stream.  Same bits as without; own_keep_per_row = 0 switches it off
+ *                        would wait for the bulk stream.  Same bits as without; own_keep_per_row = 0 switches it off.
+ *                        "own_keep_pipe_pct" (default 0): the kept share in per cent of the rule's once the pipelined candidate stages of
+ *                        gp_fit_predict / gp_fit_grad share the bulk stream's CUs
  *   "small_m"            up to this many candidates (default 8, 0 = never) are solved as matrix-vector work bound by one read of L
  *                        (csrc/smallm.hip: the acquisition optimiser's one-row calls) instead of through the 128-row tile path;
  *                        gp_predict_full_cov / gp_posterior_samples always take the tile path

@@ -420,7 +420,10 @@ def estimate_L(model, bounds, storehistory=True):
         return -np.sqrt((jac * jac).sum(1))
 
     box = np.asarray(list(bounds), dtype=float)
-    draws = np.random.uniform(size=(500, box.shape[0])) * (box[:, 1] - box[:, 0]) + box[:, 0]
+    # the global generator is consumed as the reference consumes it -- 500 values for the first variable, then 500 for the
+    # second, ... (util/general.py:63-73) -- so that a seeded run starts L-BFGS from the reference's point
+    unit = np.random.uniform(size=(box.shape[0], 500))
+    draws = (box[:, :1] + (box[:, 1:] - box[:, :1]) * unit).T
     pool = np.vstack([draws, model.X])
     start = pool[np.argmin(neg_slope(pool))]
     polished = minimize(lambda p: float(neg_slope(p).ravel()[0]), start, method='L-BFGS-B', bounds=[tuple(b) for b in box],
@@ -455,14 +458,19 @@ class LocalPenalization(object):
         lp.update_batches(None, None, None)
         return batch
 
-    def compute_batch_from_table(self, table, sense=+1, devices=None):
+    def compute_batch_from_table(self, table, sense=+1, devices=None, lipschitz=None):
         """The candidate-table variant the thesis driver uses (run.py:1234-1258): ``batch_size`` distinct rows of ``table`` by
-        repeated arg-best of the penalised acquisition; ``devices``: scored on several GPUs from this one process."""
+        repeated arg-best of the penalised acquisition; ``devices``: scored on several GPUs from this one process.
+        ``lipschitz``: a constant estimated earlier for the same model (run.py re-estimates the same L for each of its
+        three acquisitions, :1244); None estimates it here, after the first row, as the driver does."""
         lp = self.acquisition
         lp.update_batches(None, None, None)
         rows = [lp.argbest(table, sense, devices=devices)[0]]
         if self.batch_size >= 2:
-            lipschitz, best_seen = self._constants()
+            if lipschitz is None:
+                lipschitz, best_seen = self._constants()
+            else:
+                best_seen = self.acquisition.model.model.Y.min()
             while len(rows) < self.batch_size:
                 lp.update_batches(np.atleast_2d(table[rows]), lipschitz, best_seen)
                 rows.append(lp.argbest(table, sense, exclude=rows, devices=devices)[0])

@@ -90,9 +90,13 @@ int ensure_grad_buffers(gp_ctx *g, long elemsBeta, long M) {
 }
 
 // predictive gradients of all resident candidates into dDm [M, D, P] and dDv [M, D]
+// A Gower model (gp_set_gower) gets what the fork computes for it (gp.py:407-454 over stationary.py:336-364): K(Xs, X) -- and
+// with it beta -- takes the Gower branch (stationary.py:116-135), while gradients_X stays the Euclidean formula on the
+// kernel's own lengthscale parameter (_inv_dist :251-258, dK_dr_via_X :142-148).  kp.ls holds that parameter, kp.gdiv the
+// ranges: cross_k reads the latter, predict_grad_kernel the former.  Inconsistent as a derivative, but it is the function
+// the reference's L-BFGS (run.py:1206-1225) and estimate_L (run.py:1244) see.
 int run_predict_grad(gp_ctx *g) {
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
-    if (g->kp.gower) return fail(GP_ERR_STATE, "predictive gradients of the Gower kernel are not replicated");
     if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
     int rc;
     if ((rc = ensure_wi(g))) return rc;

@@ -123,7 +123,7 @@ class GPModel(BOModel):
     def copy(self):
         twin = GPModel(kernel=self.model.kern.copy(), noise_var=self.noise_var, exact_feval=self.exact_feval,
                        optimizer=self.optimizer, max_iters=self.max_iters, optimize_restarts=self.optimize_restarts,
-                       verbose=self.verbose, ARD=self.ARD, device=self.device)
+                       verbose=self.verbose, ARD=self.ARD, Gower=self.Gower, space=self.space, device=self.device)
         twin._create_model(self.model.X, self.model.Y)
         twin.updateModel(self.model.X, self.model.Y, None, None)
         return twin

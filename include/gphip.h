@@ -75,7 +75,11 @@ int gp_set_params(gp_t *gp, int kernel, int ard, double variance, const double *
 
 /* The fork's mixed-variable "Gower" covariance (GPy/GPy/kern/src/stationary.py:116-135 of the reference tree):
  * K = prod_d K_of_r(r_d), r_d = |x_d - x'_d| / range[d] on continuous dimensions and (x_d != x'_d) on discrete
- * ones (is_discrete[d] != 0).  enable = 0 restores the Euclidean kernel.  Kdiag remains `variance`, as in the fork. */
+ * ones (is_discrete[d] != 0).  enable = 0 restores the Euclidean kernel.  Kdiag remains `variance`, as in the fork.
+ * Predictive gradients of a Gower model (gp_predict_grad, gp_acq_grad, gp_acq_lp_grad) are the fork's: Euclidean
+ * Stationary.gradients_X on the kernel's own lengthscale (stationary.py:336-364, _inv_dist :251-258) with the Gower
+ * K(Xs, X) inside dv/dx (gp.py:451-452) -- what run.py:1206-1225,1244 runs L-BFGS and estimate_L on.  gp_lml_grad and
+ * gp_fit_grad return GP_ERR_STATE for a Gower model (the host differentiates the device LML numerically). */
 int gp_set_gower(gp_t *gp, int enable, const int *is_discrete, const double *range);
 
 /* ---- fit ---------------------------------------------------------------

@@ -810,3 +810,101 @@ def lp_compute_batch(acquisition, batch_size):
         k += 1
     acquisition.update_batches(None, None, None)
     return X_batch
+
+
+# ----------------------------------------------------------------------------
+# The fork's mixed-variable design space and the thesis driver's table loop
+# ----------------------------------------------------------------------------
+class MixedSpace(object):
+    """The four ``Design_space`` methods the Gower path calls, for one-dimensional continuous / discrete variables
+    given as GPyOpt domain dictionaries: ``lengthscales`` (GPyOpt/GPyOpt/core/task/space.py:351-362: range of every
+    continuous variable, in order), ``get_continuous_dims`` (:436-445), ``get_discrete_dims`` (:483-492),
+    ``get_bounds`` (:263-272 over core/task/variables.py:91-92,169-170: a discrete variable's bounds are (min, max) of its
+    domain)."""
+
+    def __init__(self, domain):
+        self.domain = [dict(d) for d in domain]
+        for d in self.domain:
+            assert d["type"] in ("continuous", "discrete") and int(d.get("dimensionality", 1)) == 1
+        self.dimensionality = len(self.domain)
+
+    def lengthscales(self):
+        return [d["domain"][-1] - d["domain"][0] for d in self.domain if d["type"] == "continuous"]
+
+    def get_continuous_dims(self):
+        return [i for i, d in enumerate(self.domain) if d["type"] == "continuous"]
+
+    def get_discrete_dims(self):
+        return [i for i, d in enumerate(self.domain) if d["type"] == "discrete"]
+
+    def get_bounds(self):
+        return [(min(d["domain"]), max(d["domain"])) if d["type"] == "discrete" else tuple(d["domain"])
+                for d in self.domain]
+
+    def draw(self, rng, n):
+        """n uniform rows of the mixed domain (test inputs; not a reference function)."""
+        cols = [rng.choice(np.asarray(d["domain"], dtype=float), n) if d["type"] == "discrete"
+                else rng.uniform(d["domain"][0], d["domain"][1], n) for d in self.domain]
+        return np.stack(cols, axis=1)
+
+
+class OracleLP(object):
+    """AcquisitionLP over the oracle model (GPyOpt/GPyOpt/acquisitions/LP.py:26-140) with EI / LCB / MPI as the base
+    acquisition: ``update_batches`` :41-47, ``acquisition_function`` :105-110, ``acquisition_function_withGradients``
+    :135-140.  ``base`` in {"EI", "LCB", "MPI"}; LCB switches the transform to softplus (:31-32)."""
+
+    def __init__(self, model, space, base="EI", par=None, transform="none"):
+        self.model, self.space, self.base = model, space, base
+        self.par = par if par is not None else {"EI": 0.01, "LCB": 2.0, "MPI": 0.01}[base]
+        self.transform = "softplus" if (base == "LCB" and transform == "none") else transform
+        self.X_batch = self.r_x0 = self.s_x0 = None
+
+    def _neg_base(self, x):
+        f = {"EI": acq_EI, "LCB": acq_LCB, "MPI": acq_MPI}[self.base]
+        return acquisition_function(f(self.model, x, self.par))
+
+    def _neg_base_withGradients(self, x):
+        f = {"EI": acq_EI_withGradients, "LCB": acq_LCB_withGradients, "MPI": acq_MPI_withGradients}[self.base]
+        a, da = f(self.model, x, self.par)
+        return -a, -da     # base.py:42-50 with unit cost and no constraints
+
+    def update_batches(self, X_batch, L, Min):
+        self.X_batch = X_batch
+        if X_batch is not None:
+            self.r_x0, self.s_x0 = lp_hammer_precompute(self.model, X_batch, L, Min)
+
+    def acquisition_function(self, x):
+        return lp_penalized_acquisition(self._neg_base(x), x, self.X_batch, self.r_x0, self.s_x0, self.transform)
+
+    def acquisition_function_withGradients(self, x):
+        x = np.atleast_2d(x)
+        neg, dneg = self._neg_base_withGradients(x)
+        return self.acquisition_function(x), lp_d_acquisition(neg, dneg, x, self.X_batch, self.r_x0, self.s_x0,
+                                                              self.transform)
+
+
+def lp_table_batch(lp, configurations, batch_size):
+    """The thesis driver's batch over a table of feasible configurations, run.py:1234-1258: the un-penalised arg-MAX of
+    ``AcquisitionLP.acquisition_function`` (:1239-1241), then ``estimate_L`` on the GP and ``Min = model.Y.min()``
+    (:1244-1245), then ``batch_size - 1`` rounds of update_batches / masked arg-max (:1246-1256).  Returns
+    (row indices, L, Min).  ``lp`` offers update_batches, acquisition_function, model.model and space.get_bounds()."""
+    suggested = []
+    lp.update_batches(None, None, None)
+    acquisition_values = lp.acquisition_function(configurations)
+    index_best = int(np.argmax(acquisition_values))
+    suggested.append(index_best)
+    X_batch = configurations[index_best]
+    get = 1
+    L = estimate_L(lp.model.model, lp.space.get_bounds())
+    Min = lp.model.model.Y.min()
+    while get < batch_size:
+        lp.update_batches(X_batch, L, Min)
+        acquisition_values = lp.acquisition_function(configurations)
+        masked = np.ma.array(acquisition_values, mask=False)
+        for existing_index in suggested:
+            masked.mask[existing_index] = True
+        index_best = int(np.argmax(masked))
+        suggested.append(index_best)
+        X_batch = np.vstack((X_batch, configurations[index_best]))
+        get += 1
+    return suggested, L, Min

@@ -320,6 +320,51 @@ def check_lp_evaluator(A):
     return note
 
 
+def check_gower_space_and_table_loop(A):
+    """The fork's mixed design space and the table loop of run.py:1234-1258 under the Gower kernel:
+    (1) the reference's verbatim ``Design_space`` (GPyOpt/GPyOpt/core/task/space.py) against ``O.MixedSpace`` on the four
+    methods the path calls; (2) the loop driven by the reference's verbatim AcquisitionLP / AcquisitionEI / AcquisitionLCB
+    objects on an oracle-backed Gower model against the same loop driven by ``O.OracleLP`` -- identical rows, L and final
+    score vector."""
+    import importlib
+    space_mod = importlib.import_module("GPyOpt.core.task.space")
+    domains = [
+        [{'name': 'a', 'type': 'discrete', 'domain': (0, 1, 2, 3)}, {'name': 'x', 'type': 'continuous', 'domain': (-2.0, 5.0)},
+         {'name': 'b', 'type': 'discrete', 'domain': (10, 20)}, {'name': 'y', 'type': 'continuous', 'domain': (0.0, 0.5)}],
+        [{'name': 'm', 'type': 'discrete', 'domain': tuple(range(5))}, {'name': 'p', 'type': 'discrete', 'domain': tuple(range(7))},
+         {'name': 'q', 'type': 'discrete', 'domain': (0, 1, 2)}, {'name': 'r', 'type': 'discrete', 'domain': (0, 1)},
+         {'name': 'c', 'type': 'continuous', 'domain': (12.0, 48.0)}, {'name': 'l', 'type': 'continuous', 'domain': (25.4, 100.0)}]]
+    for dom in domains:
+        ref, mine = space_mod.Design_space(dom), O.MixedSpace(dom)
+        assert ref.lengthscales() == mine.lengthscales()
+        assert ref.get_continuous_dims() == mine.get_continuous_dims()
+        assert ref.get_discrete_dims() == mine.get_discrete_dims()
+        assert ref.get_bounds() == mine.get_bounds()
+    dom = domains[1]
+    ref, mine = space_mod.Design_space(dom), O.MixedSpace(dom)
+    rng = np.random.default_rng(8)
+    X, table = mine.draw(rng, 70), mine.draw(rng, 400)
+    Y = O.normalize(np.sin(X[:, 4:5] / 6.0) + 0.2 * X[:, 0:1] - 0.1 * (X[:, 2:3] == 1) + 0.02 * rng.standard_normal((70, 1)))
+    worst = 0.0
+    for base, cls_key, kw in (("EI", "EI", dict(jitter=0.01)), ("LCB", "LCB", dict(exploration_weight=2))):
+        gp = O.OracleGP(X, Y, O.make_kernel("Mat52", 6, 0.9, [1.5], Gower=True, space=ref), 1e-6)
+        gm = O.OracleGPModel(gp)
+        gm.analytical_gradient_prediction = True
+        cls = getattr(A[cls_key], "Acquisition" + cls_key)
+        lp_ref = A["LP"].AcquisitionLP(gm, ref, None, cls(gm, ref, None, None, **kw))
+        lp_mine = O.OracleLP(gm, mine, base)
+        assert lp_ref.transform == lp_mine.transform
+        np.random.seed(21)
+        rows_ref, L_ref, Min_ref = O.lp_table_batch(lp_ref, table, 5)
+        np.random.seed(21)
+        rows_mine, L_mine, Min_mine = O.lp_table_batch(lp_mine, table, 5)
+        assert rows_ref == rows_mine and L_ref == L_mine and Min_ref == Min_mine
+        a, b = lp_ref.acquisition_function(table), lp_mine.acquisition_function(table)
+        worst = max(worst, float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(a)))))
+    assert worst < 1e-13, worst
+    return "Design_space verbatim == MixedSpace; table loop on verbatim AcquisitionLP == OracleLP (rows, L; scores %.1e)" % worst
+
+
 def main():
     if not ref_leaf.available():
         print("reference tree absent: cannot pin"); return 2
@@ -334,6 +379,7 @@ def main():
     A = ref_leaf.load_acquisitions()
     print(check_acquisitions(A))
     print(check_lp_evaluator(A))
+    print(check_gower_space_and_table_loop(A))
     print("ORACLE PINNED")
     return 0
 

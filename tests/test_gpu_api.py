@@ -390,8 +390,12 @@ def test_gower_mixed_variable_kernel():
         mu0, v0 = gp.predict(Xs)
         np.testing.assert_allclose(mu, mu0, rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(v, v0, rtol=1e-6, atol=1e-9)
-        with pytest.raises(RuntimeError, match="Gower"):
-            m.predictive_gradients(Xs[:2])
+        # the fork's pairing: Gower K inside Euclidean gradients_X on the kernel's own lengthscale (gp.py:407-454 over
+        # stationary.py:336-364); rows 0..4 sit on training points (inverse distance 0 there, stationary.py:251-258)
+        dm, dv = m.predictive_gradients(Xs[:12])
+        dm0, dv0 = gp.predictive_gradients(Xs[:12])
+        np.testing.assert_allclose(dm, dm0, rtol=1e-6, atol=1e-6 * np.max(np.abs(dm0)))
+        np.testing.assert_allclose(dv, dv0, rtol=1e-6, atol=1e-6 * np.max(np.abs(dv0)))
         m.close()
     # through GPyOpt's front door, as run.py:1207-1224 builds it (Gower=True, exact_feval=True, no optimisation here)
     gm = gpo.GPModel(exact_feval=True, max_iters=0, Gower=True, space=space, verbose=False)

@@ -76,3 +76,39 @@ def test_posterior_covariance_between_points_reference_golden():
     gp = O.OracleGP(X1, Y, Poly(), noise_var=1.0)   # GPRegression default noise_var = 1 (gp_regression.py:29)
     result = gp.posterior_covariance_between_points(X1, X2)
     assert np.allclose(result, np.array([[0.4, 2.2], [1.0, 1.0]]) / 3.0)
+
+
+def _gower():
+    import json
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gp_gower.npz"))
+    dom = json.loads(str(g["domain_json"]))
+    return g, dom, sorted({k.split("/")[0] for k in g.files if k.startswith("G_")})
+
+
+@pytest.mark.parametrize("tag", [t for t in _gower()[2] if "_N64_" in t or "_N150_" in t])
+def test_oracle_matches_gower_golden(tag):
+    """The Gower fixture (made through the reference's verbatim Design_space and leaf modules) from the oracle alone:
+    posterior, the fork's predictive gradients, estimate_L under the fixture's seed, the run.py:1234-1258 rows."""
+    g, dom, _ = _gower()
+    c = Case(g, tag)
+    space = O.MixedSpace(dom)
+    kern = O.make_kernel("rbf" if int(c.kernel) == 0 else "Mat52", 6, float(c.variance), c.lengthscale, Gower=True,
+                         space=space)
+    gp = O.OracleGP(c.X, c.Y, kern, float(c.noise))
+    assert np.array_equal(gp.posterior["K"][c.rows], c.K_rows)
+    assert gp.posterior["lml"] == float(c.lml)
+    mu, var = gp.predict(c.Xs)
+    assert np.array_equal(mu, c.mu) and np.array_equal(var, c.var)
+    dm, dv = gp.predictive_gradients(c.Xs)
+    np.testing.assert_allclose(dm, c.dmdx, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(dv, c.dvdx, rtol=1e-12, atol=1e-300)
+    gm = O.OracleGPModel(gp)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for base in ("EI", "LCB"):
+            lp = O.OracleLP(gm, space, base)
+            np.random.seed(int(c.np_seed))
+            rows, L, Min = O.lp_table_batch(lp, c.table, 5)
+            assert rows == [int(i) for i in getattr(c, "lp_rows_" + base)]
+            np.testing.assert_allclose(L, float(c.L), rtol=1e-12)
+            assert Min == float(c.Min)

@@ -33,6 +33,13 @@ def test_acquisition_layer_verbatim():
     assert "compute_batch verbatim == oracle" in pin.check_lp_evaluator(A)
 
 
+@needs_ref
+def test_gower_space_and_table_loop_verbatim():
+    """The reference's own Design_space and AcquisitionLP driving the run.py:1234-1258 loop under the Gower kernel."""
+    A = ref_leaf.load_acquisitions()
+    assert "table loop on verbatim AcquisitionLP == OracleLP" in pin.check_gower_space_and_table_loop(A)
+
+
 def test_reference_test_invariants():
     # pinv closed form, var >= 0, normaliser equivalence, finite-difference gradients (no reference import needed)
     pin.check_invariants()

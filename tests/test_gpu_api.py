@@ -279,17 +279,32 @@ def test_local_penalization_matches_reference_formulas(base):
     gm.model.close()
 
 
-def test_local_penalization_batch_from_table():
-    np.random.seed(3)
+@pytest.mark.parametrize("base", ["EI", "LCB"])
+def test_local_penalization_batch_from_table(base):
+    """The thesis driver's loop (run.py:1234-1258) on a fixed table: the rows the device loop picks == the rows the oracle's
+    restatement of that loop picks (O.lp_table_batch over O.OracleLP, pinned to the reference's verbatim AcquisitionLP in
+    oracle/pin_against_reference.py), same numpy seed for estimate_L; EI (plain log) and LCB (softplus)."""
     X, Y, table = O.synthetic_problem(120, 2, 4000, seed=12)
     gm = gpo.GPModel(kernel=gpo.kern.Matern52(2, 1.0, 0.3), noise_var=0.01, max_iters=0, verbose=False)
     gm.updateModel(X, Y, None, None)
+    gp0, gm0 = _oracle_twin(X, Y, "Mat52", [0.3], 1.0, 0.01)
     space = gpo.Design_space([{'name': 'x', 'type': 'continuous', 'domain': (0, 1), 'dimensionality': 2}])
-    lp = gpo.AcquisitionLP(gm, space, None, gpo.AcquisitionEI(gm, space))
+    cls = {"EI": gpo.AcquisitionEI, "LCB": gpo.AcquisitionLCB}[base]
+    lp = gpo.AcquisitionLP(gm, space, None, cls(gm, space))
+    lp0 = O.OracleLP(gm0, space, base)
+    np.random.seed(3)
+    want, L0, Min0 = O.lp_table_batch(lp0, table, 5)
+    np.random.seed(3)
     L = gpo.estimate_L(gm.model, space.get_bounds())
-    assert L > 0
+    assert abs(L - L0) <= 1e-3 * L0       # polished by forward differences of step 1e-8: see test_gpu_gower.py
+    np.random.seed(3)
     chosen = gpo.LocalPenalization(lp, 5).compute_batch_from_table(table, sense=+1)
-    assert len(chosen) == 5 and len(set(chosen)) == 5
+    assert len(set(chosen)) == 5
+    final = lp0.acquisition_function(table)               # the oracle's last penalised score vector
+    for got, ref in zip(chosen, want):
+        assert got == ref or abs(final[got] - final[ref]) <= 1e-6 * max(1.0, abs(final[ref])), (chosen, want)
+    # with the oracle's L handed in the rows are the oracle's whatever the polish did
+    assert gpo.LocalPenalization(lp, 5).compute_batch_from_table(table, sense=+1, lipschitz=L0) == want
     gm.model.close()
 
 

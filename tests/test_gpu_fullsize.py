@@ -212,6 +212,71 @@ def test_c4_one_shard_matern_125k_candidates():
     h.close()
 
 
+def test_c4_full_table_through_a_device_group(mode):
+    """C4 at size: ONE fit of N=16384, D=8 Matern-5/2 replicated over eight group members and the whole 10^6-row table split
+    over them (125 000 rows each -- the per-GPU workload of BASELINE.json's configs[3]) from one process, against the same
+    table through a single context: arg-best, top-5 (anchor_points_generator.py:59-61), a cross-block tie (NumPy's lowest
+    index, run.py:1241), and the local-penalisation arg-max with taken rows on both sides of block boundaries
+    (run.py:1249-1252).  The eight members share device 0 here (the box has one GPU): the split / remainder / merge logic is
+    what this exercises at size; on an 8-GPU node the same call runs one member per device."""
+    if mode:
+        pytest.skip("the group's split / merge logic does not depend on the arithmetic mode; run once (true fp64)")
+    N, D, M = 16384, 8, 1000000
+    X, Y, _ = O.synthetic_problem(N, D, 8, seed=1234)
+    Xs = np.random.default_rng(78).uniform(0, 1, (M, D))
+    par = (_lib.GP_KERNEL_MATERN52, 0, 1.0, O.default_lengthscale(D, False), 1e-2)
+    h = _lib.Handle(0)
+    h.set_data(X, Y)
+    h.set_params(*par)
+    lml, _, jit = h.fit()
+    fmin = h.fmin()
+    grp = _lib.Group((0,) * 8)
+    grp.set_data(X, Y)
+    grp.set_params(*par)
+    glml, _, gjit = grp.fit()
+    assert glml == lml and gjit == jit == 0.0 and grp.fmin() == fmin
+    EI = _lib.GP_ACQ_EI
+
+    h.set_candidates(Xs)
+    grp.set_candidates(Xs)
+    one = h.acq_argbest(EI, 0.01, fmin, -1)
+    assert grp.acq_argbest(EI, 0.01, fmin, -1) == one
+    ti, tv = h.acq_topk(EI, 0.01, fmin, -1, 5)
+    gi, gv = grp.acq_topk(EI, 0.01, fmin, -1, 5)
+    assert np.array_equal(gi, ti) and np.array_equal(gv, tv) and ti[0] == one[0]
+    a = h.acq(EI, 0.01, fmin)[:, 0]
+    order = np.argsort(a, kind="stable")[:5]
+    assert np.array_equal(ti, order) and np.array_equal(tv, a[order])
+    # local penalisation around the first two anchors; rows taken on both sides of every block boundary + the winner
+    Xb = Xs[ti[:2]]
+    r0, s0 = np.array([0.05, 0.08]), np.array([0.02, 0.03])
+    taken = sorted({int(one[0])} | {b * 125000 + o for b in range(1, 8) for o in (-1, 0)} | {0, M - 1})
+    lp1 = h.acq_lp_argbest(EI, 0.01, fmin, 0, +1, Xb=Xb, r_x0=r0, s_x0=s0, exclude=taken)
+    lpg = grp.acq_lp_argbest(EI, 0.01, fmin, 0, +1, Xb=Xb, r_x0=r0, s_x0=s0, exclude=taken)
+    assert lpg == lp1 and lp1[0] not in taken
+    v = h.acq_lp(EI, 0.01, fmin, 0, Xb=Xb, r_x0=r0, s_x0=s0)
+    mv = np.ma.array(v, mask=False)
+    mv.mask[taken] = True
+    assert lp1[0] == int(np.argmax(mv)) and lp1[1] == v[lp1[0]]
+    # a tie across blocks: the winner's row copied into a lower block and a higher one -> the lowest index wins
+    w = int(one[0])
+    lo = w - 125000 if w >= 125000 else w             # the same row one block down / in the last block (when there is one)
+    hi = 875000 + w % 125000 if w < 875000 else w
+    Xt = Xs.copy()
+    Xt[lo] = Xs[w]
+    Xt[hi] = Xs[w]
+    h.set_candidates(Xt)
+    grp.set_candidates(Xt)
+    t1 = h.acq_argbest(EI, 0.01, fmin, -1)
+    assert grp.acq_argbest(EI, 0.01, fmin, -1) == t1 and t1[0] == lo and t1[1] == one[1]
+    gi2, gv2 = grp.acq_topk(EI, 0.01, fmin, -1, 5)
+    ti2, tv2 = h.acq_topk(EI, 0.01, fmin, -1, 5)
+    same = sorted({lo, w, hi})
+    assert np.array_equal(gi2, ti2) and np.array_equal(gv2, tv2) and list(ti2[:len(same)]) == same
+    grp.close()
+    h.close()
+
+
 def test_c5_lml_and_gradients_n32768_ard():
     """C5: N=32768, D=16 ARD-RBF, LML + (D+2) gradients.  Gradient entries are checked against central
     differences of the device LML itself (the reference's model_tests.py:684-723 does the same through

@@ -192,7 +192,24 @@ def test_stress_case_against_extended_precision_truth(golden, h, tag):
             recorded[key] = {"hip": float(np.max(np.abs(dev_val - truth))) / sc(truth),
                              "lapack_reference": float(np.max(np.abs(getattr(c, key) - truth))) / sc(truth),
                              "north_star_tol": None, "amplification_u2": float(np.max(u * u))}
+    # the DECISION these cases lead to (anchor_points_generator.py:59-61, run.py:1241): the row the device's arg-best
+    # picks, fed by the device's own fmin as in a live loop, against the row the reference picks (fixture argmin_*).
+    # Where they differ the reference's own scores must not be able to tell the two rows apart: their gap is below the
+    # distance of either float64 path to the extended-precision truth.  Agreement is recorded per case and acquisition
+    # (profiles/r05_stress_decisions.txt is the tally).
+    decisions = {}
+    for typ, par, name in ((_lib.GP_ACQ_EI, 0.01, "EI"), (_lib.GP_ACQ_LCB, 2.0, "LCB"), (_lib.GP_ACQ_MPI, 0.01, "MPI")):
+        idx, _ = h.acq_argbest(typ, par, fmin, -1)
+        ir = int(getattr(c, "argmin_" + name))
+        ref, tr = getattr(c, "neg_" + name)[:, 0], getattr(t, "neg_" + name)[:, 0]
+        dev = h.acq(typ, par, fmin)[:, 0]
+        e_hip, e_ref = float(np.max(np.abs(dev - tr))), float(np.max(np.abs(ref - tr)))
+        gap = float(abs(ref[idx] - ref[ir]))
+        decisions[name] = {"device_row": int(idx), "reference_row": ir, "truth_row": int(np.argmin(tr)), "agree": idx == ir,
+                           "reference_gap": gap, "hip_to_truth": e_hip, "lapack_to_truth": e_ref}
+        assert idx == ir or gap <= min(e_hip, e_ref), (name, decisions[name])
     report, bad = dict(recorded), []
+    report["decisions"] = decisions
     for name, hip, ref, truth, scale, tol in rows:
         e_hip = float(np.max(np.abs(np.asarray(hip, dtype=float) - truth))) / scale
         e_ref = float(np.max(np.abs(np.asarray(ref, dtype=float) - truth))) / scale

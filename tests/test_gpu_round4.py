@@ -371,6 +371,12 @@ def test_local_penalization_batch_over_a_device_group():
     np.random.seed(9)                                  # estimate_L draws its sample points from numpy's global generator
     grouped = gpo.LocalPenalization(lp, 5).compute_batch_from_table(table, sense=+1, devices=[0, 0])
     assert grouped == single and len(set(single)) == 5
+    # ... and they are the rows the oracle's loop picks (run.py:1234-1258 restated, O.lp_table_batch)
+    gp0 = O.OracleGP(X, Y, O.make_kernel("Mat52", 2, 1.0, [0.3]), 0.01)
+    lp0 = O.OracleLP(O.OracleGPModel(gp0), space, "EI")
+    np.random.seed(9)
+    want, L0, _ = O.lp_table_batch(lp0, table, 5)
+    assert gpo.LocalPenalization(lp, 5).compute_batch_from_table(table, sense=+1, devices=[0, 0], lipschitz=L0) == want
     # a penalised arg-best with exclusions straddling both blocks, and every row of one block taken
     lp.update_batches(table[[10, 2500]], 3.0, float(Y.min()))
     taken = [int(i) for i in (0, 1499, 1500, 1501, 3000)]

@@ -9,20 +9,22 @@ hyper-parameters fixed.
     through ONE call (gp_fit_predict; --separate-calls times gp_fit + gp_predict instead), + EI scoring + device
     arg-best (A9-A11, A14).  value = iterations/s.
 
---gpus N > 1        workload C4 = BASELINE.json configs[3]: N=16384, D=8 Matern-5/2, ONE candidate table of 10^6 rows
-    split over the ranks (contiguous row blocks), per iteration: fit (replicated on every rank: the fit does not shard,
-    SURVEY.md 8e) + posterior + EI over the rank's block + device arg-best + ONE RCCL all-gather of the per-rank
-    (best value, global row) pair over xGMI + the lowest-index merge.  Total work is fixed as N grows ("strong" -- of
-    the predict/EI part; the fit's share is reported separately and does not scale).  value = whole sharded
-    iterations/s (NOT multiplied by the rank count).  One process per GPU: either launched by torch.distributed.run
-    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- called plainly as `python bench.py --gpus N`
-    -- this process becomes a launcher that makes NO HIP / RCCL call itself and starts N fresh rank processes
-    (launch_ranks below; never a re-exec of a process that touched the GPU).  No rank imports torch: the 128-byte RCCL
-    unique id and the end-of-run records travel over a local socket between the ranks (Rendezvous below), and with the
-    RCCL communicator up the barrier and the max-over-ranks of the elapsed time are all-gathers inside libgphip
-    (gp_comm_allgather_best); the JSON line records which librccl the process mapped and the version it reports.  The ranks
-    compare their merged winners at the end; a disagreement is exit code 3.  --workload c3|c4 overrides the automatic
-    choice (e.g. C4 on one GPU as the strong-scaling base).
+--gpus N > 1        the SAME workload, strong scaling: one model, the same table of 10 000 candidates (seed 1236, the table
+    of the N = 1 run) split over the ranks in contiguous row blocks.  Per iteration every rank refits the model (the fit does
+    not shard: replicas only; a broadcast of the 2.1 GB factor from one fitting rank would take longer than
+    the 28 ms refit it saves -- gp_comm_bcast_fit exists for callers who fit elsewhere), scores its block, reduces a
+    device arg-best, and ONE RCCL all-gather of the per-rank (best value, global row) pair over xGMI + the lowest-index
+    merge give every rank the job's winner -- the winner of the N = 1 run.  value = job iterations/s (NOT multiplied by
+    the rank count); expectation ~ 1 / (fit + solve / N).  BASELINE.json's own sharding
+    configuration (C4 = configs[3]: Matern-5/2, ONE table of 10^6 rows split over the ranks) is measured in the same run
+    as a second object of the line (c4_sharded); `--workload c4` runs it as the line itself.
+    One process per GPU: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment), or -- called plainly as `python bench.py --gpus N` -- this process becomes a launcher that makes NO HIP /
+    RCCL call itself and starts N fresh rank processes (launch_ranks below; never a re-exec of a process that touched the
+    GPU).  No rank imports torch: the 128-byte RCCL unique id and the end-of-run records travel over a local socket between
+    the ranks (Rendezvous below), and with the RCCL communicator up the barrier and the max-over-ranks of the elapsed time
+    are all-gathers inside libgphip (gp_comm_allgather_best); the JSON line records which librccl the process mapped and
+    the version it reports.  The ranks compare their merged winners at the end; a disagreement is exit code 3.
 """
 import argparse
 import hashlib
@@ -80,10 +82,16 @@ def launch_ranks(n, argv, child_cmd=None, poll_s=0.2, grace_s=20.0, timeout_s=No
     port = s.getsockname()[1]
     s.close()   # (the ranks rendezvous over a socket file keyed by this number and the launcher's PID, not over the port)
     cmd = list(child_cmd) if child_cmd is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    # the ranks' control channel lives in a directory only this user can enter, under a key nobody can guess (the channel
+    # carries pickled objects: a predictable socket name in the shared temp directory would let another local user answer it)
+    import secrets
+    rdv_dir = tempfile.mkdtemp(prefix="gphip_bench_")
+    rdv_key = secrets.token_hex(16)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GPHIP_BENCH_LAUNCHED="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GPHIP_BENCH_LAUNCHED="1", GPHIP_BENCH_RDV_DIR=rdv_dir,
+                   GPHIP_BENCH_RDV_KEY=rdv_key)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this host driver
         procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
 
@@ -123,16 +131,39 @@ def launch_ranks(n, argv, child_cmd=None, poll_s=0.2, grace_s=20.0, timeout_s=No
     finally:
         for sg, h in previous.items():
             signal.signal(sg, h)
+        import shutil
+        shutil.rmtree(rdv_dir, ignore_errors=True)
     for p in procs:
         if p.returncode not in (None, 0) and rc == 0:
             rc = p.returncode
     return rc if rc >= 0 else 128 - rc   # a signal's negative code as the shell reports it
 
 
+def rendezvous_place():
+    """(authkey, socket path) of the ranks' control channel.  Started by bench.py's own launcher: the private directory and
+    the random key it made (GPHIP_BENCH_RDV_DIR / GPHIP_BENCH_RDV_KEY).  Started by torch.distributed.run: a per-user
+    directory under the temp directory, created 0700 and REFUSED unless it is a real directory owned by this user with no
+    access for anybody else; the key is derived from the agent's run id, MASTER_PORT and the agent's PID."""
+    port, ppid = os.environ.get("MASTER_PORT", "0"), os.getppid()
+    d, k = os.environ.get("GPHIP_BENCH_RDV_DIR"), os.environ.get("GPHIP_BENCH_RDV_KEY")
+    if not d:
+        d = os.path.join(tempfile.gettempdir(), "gphip_bench_uid%d" % os.getuid())
+        try:
+            os.mkdir(d, 0o700)
+        except FileExistsError:
+            pass
+        k = hashlib.sha256(("%s|%s|%d" % (os.environ.get("TORCHELASTIC_RUN_ID", ""), port, ppid)).encode()).hexdigest()
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("rendezvous directory %s is not a private directory of this user" % d)
+    return k.encode(), os.path.join(d, "rdv_%s_%d.sock" % (port, ppid))
+
+
 class Rendezvous(object):
-    """The ranks' control channel on ONE node, without torch: rank 0 listens on a socket file in the temp directory, named by
-    MASTER_PORT and the PID of the process that started the ranks (bench.py's launcher or torch.distributed.run: the same
-    parent for every rank), the others connect to it.  It carries small Python objects only -- the 128-byte RCCL unique id,
+    """The ranks' control channel on ONE node, without torch: rank 0 listens on a socket file in a private directory
+    (rendezvous_place), named by MASTER_PORT and the PID of the process that started the ranks (bench.py's launcher or
+    torch.distributed.run: the same parent for every rank), the others connect to it.  It carries small Python objects only -- the 128-byte RCCL unique id,
     flags, the end-of-run records, and the (value, row) pairs when no RCCL communicator can be built; the data path's
     collective is RCCL inside libgphip.  (MASTER_PORT itself is not bound: under torch.distributed.run the agent's own store
     listens there.)"""
@@ -140,8 +171,7 @@ class Rendezvous(object):
     def __init__(self, rank, world, timeout_s=120.0):
         from multiprocessing.connection import Client, Listener
         self.rank, self.world = rank, world
-        key = ("gphip-bench-%s" % os.environ.get("MASTER_PORT", "0")).encode()
-        path = os.path.join(tempfile.gettempdir(), "gphip_bench_%s_%d.sock" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        key, path = rendezvous_place()
         self.path = path
         self.peers = []
         if rank == 0:
@@ -340,11 +370,17 @@ def small_calls(sizes=(512, 2048, 16384), rows=(1, 5, 1000), reps=20, cpu=True):
         for M in rows:
             Xs = rng.uniform(0, 1, (M, D))
 
+            # up to 8 locations go down as ONE call taking them by value (gp_predict_rows / gp_acq_rows: what the host layer
+            # issues for them); more than that is gp_set_candidates + the batched call
             def dev_predict():
+                if M <= 8:
+                    return h.predict_rows(Xs, True)
                 h.set_candidates(Xs)
                 return h.predict(True)
 
             def dev_grad():
+                if M <= 8:
+                    return h.acq_rows(Xs, _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
                 h.set_candidates(Xs)
                 return h.acq_grad(_lib.GP_ACQ_EI, 0.01, fmin)
 
@@ -354,7 +390,7 @@ def small_calls(sizes=(512, 2048, 16384), rows=(1, 5, 1000), reps=20, cpu=True):
                 for _ in range(n):
                     fn()
                 return (time.perf_counter() - t0) / n * 1e3
-            rec = {"N": N, "M": M, "gpu_predict_ms": timed(dev_predict, reps), "gpu_acq_grad_ms": timed(dev_grad, reps)}
+            rec = {"N": N, "M": M, "gpu_acq_grad_ms": timed(dev_grad, reps), "gpu_predict_ms": timed(dev_predict, reps)}
             if cpu:
                 ncpu = 3 if N >= 8192 else reps
                 rec["cpu_predict_ms"] = timed(lambda: gm0.predict(Xs), ncpu)
@@ -448,11 +484,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (starts its own ranks) or "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
-    # Default workload at every N: the configuration the metric is quoted on (C3).  The fit does not shard (replicas only); the
-    # candidates do: on N > 1 ranks every rank scores its own 10^4 candidates of an N x 10^4 table and the ranks all-gather their
-    # arg-best over RCCL -- weak scaling, value = N x job iterations/s, so that the driver's N = 1, 2, 4, 8 series is ONE workload.
-    # BASELINE.json's candidate-sharding configuration (C4: one table of 10^6 candidates split over the ranks, strong scaling) is
-    # measured in the same run as a second object of the line (c4_sharded); `--workload c4` runs it as the line itself.
+    # Default workload at every N: the configuration the metric is quoted on (C3), as ONE job.  The fit does not shard (replicas
+    # only); the candidates do: on N > 1 ranks the SAME 10^4-row table of the N = 1 run is split over the ranks, every rank refits
+    # the model and scores its block, the ranks all-gather their arg-best over RCCL -- strong scaling, value = job iterations/s.
+    # BASELINE.json's candidate-sharding configuration (C4: one table of 10^6 candidates split over the ranks) is measured in the
+    # same run as a second object of the line (c4_sharded); `--workload c4` runs it as the line itself.
     workload = args.workload if args.workload != "auto" else "c3"
     with_c4 = args.workload == "auto" and world > 1 and not args.no_c4_section
     if world > 1:
@@ -470,17 +506,23 @@ def main():
     dev = 0 if os.environ.get("GPHIP_BENCH_SAME_DEVICE") else local_rank
     h = _lib.Handle(dev)
     h.set_option("emulate_fp64", 0)   # the headline is true fp64 whatever GPHIP_EMULATE_FP64 says (recorded in config)
+    panel_cols = 768.0                 # inverted diagonal panels: panel_tiles (default 6) x 128 columns
     if args.panel_tiles:
         h.set_option("panel_tiles", args.panel_tiles)
+        panel_cols = 128.0 * args.panel_tiles
     for kv in args.option:
         k, v = kv.split("=")
         h.set_option(k, int(v))
+        if k == "panel_tiles":
+            panel_cols = 128.0 * int(v)
     N, D = args.N, args.D
     if workload == "c3":
-        M_total = (args.M or 10000) * world          # every rank its own 10 000 candidates
-        M = args.M or 10000
-        lo = rank * M
-        X, Y, Xs = synthetic(N, D, M, cand_seed=1236 + rank)
+        M_total = args.M or 10000                    # ONE table for the whole job: the table of the N = 1 run
+        lo, hi = shard_bounds(M_total, rank, world)
+        M = hi - lo
+        X, Y, table = synthetic(N, D, M_total, cand_seed=1236)
+        Xs = table[lo:hi].copy()
+        del table
         kid, kname = _lib.GP_KERNEL_RBF, "RBF"
     else:
         M_total = args.M or 1000000
@@ -592,7 +634,7 @@ def main():
     ranks_agree, rank_records = True, None
     if rdv is not None:
         elapsed = max_over_ranks(elapsed)
-        # every rank merged the same gathered pairs: the winners must be identical (C4; C3 ranks score different tables)
+        # every rank merged the same gathered pairs: the winners must be identical
         rank_records = rdv.allgather({"rank": rank, "best_row": int(out[1]), "best_value": float(out[2]),
                                       "lml": float(out[0])})
         ranks_agree = all(r["best_row"] == rank_records[0]["best_row"] and
@@ -664,6 +706,19 @@ def main():
     cs = h.gemm_stats()
     h.profile(False)
 
+    # un-timed: the dominant kernel WITHOUT a neighbour of its own kind -- gp_fit then gp_predict as two calls (no candidate update
+    # shares the chip with a trailing update), HIP events around every launch of the symbol as in the timed region.  A rocprofv3
+    # --stats run of `bench.py --separate-calls` averages exactly these launches (profiles/r05_bench_kernel_stats_fp64.csv).
+    sep = None
+    if workload == "c3":
+        h.fit(); h.predict(True)
+        h.profile(True)
+        for _ in range(3):
+            h.fit(); h.predict(True)
+        sep = h.gemm_stats()
+        sep["busy_ms"] = h.gemm_busy()
+        h.profile(False)
+
     # N > 1, default workload: the candidate-sharding configuration in the same run (see above).  ONE table for the whole job
     # (seed 1236), this rank's contiguous block of it; rank 0 first times one pass over the WHOLE table on its own GPU (the
     # single-GPU base the sharded rate is read against) while the others wait at the barrier.
@@ -719,20 +774,24 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         job_rate = args.steps / elapsed
-        achieved = gs["flops"] / max(gs["ms"], 1e-9) / 1e9
+        achieved = gs["flops"] / max(gs["ms"], 1e-9) / 1e9              # per launch: flops / SUM of the launch durations
+        achieved_busy = gs["flops"] / max(busy_ms, 1e-9) / 1e9         # flops / UNION of the launch intervals
         traffic, traffic_src = static_traffic(N, D, M) if workload == "c3" else (None, None)
         kb_gbs = kb["bytes"] / max(kb["ms"], 1e-9) / 1e6
         if workload == "c3":
             cfg = {"workload": "C3 (BASELINE.json configs[2]): N=%d, D=%d RBF iso, fit (K, Cholesky, alpha, LML) + predict "
-                               "mean/var at M=%d candidates per GPU + EI arg-best" % (N, D, M),
-                   "candidates_per_gpu": M, "entry_point": "gp_fit_predict" if fused else "gp_fit + gp_predict"}
-            scaling, value = "weak", world * job_rate
+                               "mean/var at M=%d candidates + EI arg-best" % (N, D, M_total),
+                   "candidates_total": M_total, "candidates_this_rank": M,
+                   "entry_point": "gp_fit_predict" if fused else "gp_fit + gp_predict"}
+            # one job whatever N is: at N = 1 the work per GPU is the whole job (the contract's 'weak' and 'strong' coincide)
+            scaling, value = "strong", job_rate
             if world > 1:
-                cfg["note_n_gpus"] = ("the fit does not shard (replicas only, SURVEY.md 8e): every rank refits the same model and "
-                                      "scores its own %d candidates of an N x %d table, the ranks all-gather their arg-best; value "
-                                      "= N x job iterations/s (weak scaling: per-GPU work fixed).  The candidate-SHARDING "
-                                      "configuration (C4, one table split over the ranks, strong scaling) is measured in the same "
-                                      "run: c4_sharded" % (M, M))
+                cfg["note_n_gpus"] = ("ONE model, the N = 1 run's table of %d candidates split over %d ranks (%d here): the fit does "
+                                      "not shard (replicas only, SURVEY.md 8e), every rank refits and scores its block, the ranks "
+                                      "all-gather their arg-best over RCCL; value = job iterations/s, expected ~ 1 / (fit + "
+                                      "solve / N).  C4 (10^6-row table split over the ranks) is measured in the same run: "
+                                      "c4_sharded" % (M_total, world, M))
+                cfg["fit_ms_per_iter_not_scaling"] = round(fit_ms, 3)
         else:
             cfg = {"workload": "C4 (BASELINE.json configs[3]): N=%d, D=%d Matern-5/2 iso, fit (replicated per rank) + posterior "
                                "+ EI over ONE table of %d candidates split over %d rank(s) + device arg-best + RCCL "
@@ -762,7 +821,7 @@ def main():
                     "cand_solve_tflops": solve["flops"] / solve["ms"] / 1e9,
                     # the same phase counting what it executes: N^2 M plus the products with the inverted diagonal panels
                     # (M N x panel width; 768 columns by default) -- the rate to hold against the GEMM kernel's own
-                    "cand_solve_executed_tflops": solve["flops"] * (1.0 + 768.0 / N) / solve["ms"] / 1e9})
+                    "cand_solve_executed_tflops": solve["flops"] * (1.0 + panel_cols / N) / solve["ms"] / 1e9})
         result = {
             "metric": "GP fit+predict iters/sec at N=%d D=%d" % (N, D),
             "value": value, "unit": "fit+predict iters/s",
@@ -771,23 +830,31 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": cfg,
             "roofline": {"bound": "mfma", "kernel": GEMM_SYMBOL + " (C -= A B^T on fp64 v_mfma_f64_16x16x4_f64, 8 waves)",
-                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         # flops of the launches / the time the chip actually spent on them: the UNION of the launches' [start, end]
+                         # intervals (HIP events on the stream each launch runs on).  In gp_fit_predict ~25 launches per step overlap
+                         # (candidate updates beside the factorisation's trailing updates), so the SUM of their durations counts
+                         # shared time twice and exceeds the step itself: that figure is kept as *_per_launch.
+                         "achieved": achieved_busy, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_busy / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_provenance": traffic_src,
-                         "note": ("HIP events bracket every launch of this kernel symbol INSIDE the timed region (%.0f per step), "
-                                  % (gs["launches"] / max(args.steps, 1)) +
-                                  "on the stream each is launched on.  In gp_fit_predict a few candidate-update launches and "
-                                  "the trailing updates of the factorisation's tail run concurrently: a launch's duration "
-                                  "includes the time it shares the chip; achieved_while_running = the same flops / the union "
-                                  "of the launches' intervals") if fused else
-                                 "HIP events bracket every launch of this kernel symbol inside the timed region, on its stream",
+                         "busy_ms_total": busy_ms,
+                         "achieved_per_launch": achieved, "frac_per_launch": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "launches": gs["launches"], "kernel_ms_total": gs["ms"],
-                         "launch_filter": "every launch of that kernel symbol in the timed region (launches of >= 1400 output "
-                                          "tiles: trailing updates, candidate updates; > 90 % of the flops)",
                          "avg_launch_ms": gs["ms"] / max(gs["launches"], 1),
-                         "busy_ms_total": busy_ms, "achieved_while_running": gs["flops"] / max(busy_ms, 1e-9) / 1e9,
-                         "frac_while_running": gs["flops"] / max(busy_ms, 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS,
                          "flops_per_launch_avg": gs["flops"] / max(gs["launches"], 1),
+                         "launch_filter": "every launch of that kernel symbol in the timed region (launches of >= 1400 output "
+                                          "tiles: trailing updates, candidate updates; > 90 % of the flops), %.0f per step"
+                                          % (gs["launches"] / max(args.steps, 1)),
+                         # the same symbol with no launch of its own kind beside it: gp_fit then gp_predict, 3 un-timed passes
+                         "separate_calls_reference": None if sep is None else {
+                             "launches": sep["launches"], "kernel_ms_total": sep["ms"],
+                             "avg_launch_ms": sep["ms"] / max(sep["launches"], 1),
+                             "flops_per_launch_avg": sep["flops"] / max(sep["launches"], 1),
+                             "achieved": sep["flops"] / max(sep["ms"], 1e-9) / 1e9,
+                             "frac": sep["flops"] / max(sep["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS,
+                             "busy_ms_total": sep["busy_ms"],
+                             "rocprof": "profiles/r05_bench_kernel_stats_fp64.csv: rocprofv3 --kernel-trace --stats of "
+                                        "`bench.py --separate-calls` (every launch of the symbol un-overlapped)"},
                          # the whole step against the same peak: N^3/3 (Cholesky) + N^2 M (candidate solve) algorithmic flops of
                          # ONE rank's step / ms_per_step -- K builds, chain, reductions and launch gaps all inside the time
                          "step_algorithmic_flops": N ** 3 / 3.0 + float(N) * N * M,

@@ -17,6 +17,7 @@ from scipy.special import erfc, log_ndtr, ndtr
 from . import _lib
 from .gpmodel import GPModel
 
+_FEW_ROWS = 8            # up to this many locations go down as ONE gp_*_rows call (include/gphip.h): the L-BFGS inner loop
 _ROOT_2 = np.sqrt(2)
 _ROOT_2PI = np.sqrt(2 * np.pi)
 _STD_FLOOR = 1e-10
@@ -149,10 +150,27 @@ class AcquisitionBase(object):
         shift, scale = (0.0, 1.0) if nz is None else (float(nz.mean[0]), float(nz.std[0]))
         return gp, self._fmin(), shift, scale
 
+    def _device_few(self, x):
+        """The handful-of-locations route (what scipy's L-BFGS-B issues, optimizer.py:36-61): ``x`` as a 2-D float array when it
+        has at most ``_FEW_ROWS`` rows -- the caller then makes ONE gp_acq_rows call, locations by value -- else None.
+        Also returns what that call takes: the handle owner, fmin and the normaliser's mean / std."""
+        x = np.atleast_2d(np.asarray(x, dtype=float))
+        if x.shape[0] > _FEW_ROWS:
+            return None
+        gp = self.model.model
+        gp._ensure_fit()
+        nz = gp.normalizer
+        shift, scale = (0.0, 1.0) if nz is None else (float(nz.mean[0]), float(nz.std[0]))
+        return x, gp, self._fmin(), shift, scale
+
     # ---- the contract ----------------------------------------------------------------------------------------------
     def acquisition_function(self, x):
         """-(acq(x) * feasibility(x)) / cost(x), [M, 1]  (base.py:33-39)."""
         if self._device_ok():
+            few = self._device_few(x)
+            if few is not None:
+                x, gp, fmin, shift, scale = few
+                return gp._h.acq_rows(x, self._acq_id, self._par(), fmin, shift, scale)
             gp, fmin, shift, scale = self._device_stage(x)
             return gp._h.acq(self._acq_id, self._par(), fmin, shift, scale)
         price, _ = self.cost_withGradients(x)
@@ -161,6 +179,10 @@ class AcquisitionBase(object):
     def acquisition_function_withGradients(self, x):
         """The same value and its x-gradient [M, D]  (base.py:42-50)."""
         if self._device_ok():
+            few = self._device_few(x)
+            if few is not None:
+                x, gp, fmin, shift, scale = few
+                return gp._h.acq_rows(x, self._acq_id, self._par(), fmin, shift, scale, grad=True)
             gp, fmin, shift, scale = self._device_stage(x)
             return gp._h.acq_grad(self._acq_id, self._par(), fmin, shift, scale)
         val, dval = self._compute_acq_withGradients(x)
@@ -367,9 +389,21 @@ class AcquisitionLP(AcquisitionBase):
         batch = dict(Xb=self.X_batch, r_x0=self.r_x0, s_x0=self.s_x0, y_mean=shift, y_std=scale)
         return gp._h, head, batch
 
+    def _lp_few(self, x, grad):
+        """ONE gp_acq_rows call for up to ``_FEW_ROWS`` locations (None otherwise): the L-BFGS runs of compute_batch."""
+        few = self.acq._device_few(x)
+        if few is None:
+            return None
+        x, gp, fmin, shift, scale = few
+        lp = (1 if self.transform == 'softplus' else 0, self.X_batch, self.r_x0, self.s_x0)
+        return gp._h.acq_rows(x, self.acq._acq_id, self.acq._par(), fmin, shift, scale, grad=grad, lp=lp)
+
     def acquisition_function(self, x):
         """1-D array like the reference's (LP.py:105-110)."""
         if self._lp_device_ok():
+            few = self._lp_few(x, False)
+            if few is not None:
+                return few
             h, head, batch = self._lp_call(x)
             return h.acq_lp(*head, **batch)
         return self._score_on_host(x)
@@ -381,6 +415,9 @@ class AcquisitionLP(AcquisitionBase):
         """(value [M], gradient [M, D])  (LP.py:112-140)."""
         x = np.atleast_2d(np.asarray(x, dtype=float))
         if self._lp_device_ok():
+            few = self._lp_few(x, True)
+            if few is not None:
+                return few
             h, head, batch = self._lp_call(x)
             return h.acq_lp_grad(*head, **batch)
         neg, dneg = self.acq.acquisition_function_withGradients(x)

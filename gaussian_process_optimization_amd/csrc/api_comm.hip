@@ -102,6 +102,8 @@ static void apply_fit_record(gp_ctx *g, const double *rec) {
     g->fitted = true;
     g->fmin_valid = false;
     g->wi_valid = false;
+    g->li_valid = false;
+    g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;
     g->predicted = false;

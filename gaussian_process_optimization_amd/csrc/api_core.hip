@@ -324,9 +324,11 @@ extern "C" int gp_destroy(gp_t *g) {
     if (g->comm) ncclCommDestroy(g->comm);
     double *ptrs[] = {g->dX, g->dY, g->dA, g->dInvL, g->dAlpha, g->dW, g->dMu, g->dScal, g->dRedV,
                       g->dXs, g->dT, g->dMean, g->dVar, g->dAcq, g->dWi, g->dT2, g->dDm, g->dDv, g->dDacq, g->dCov, g->dInvP, g->dInvPw, g->dLp, g->dComm,
-                      g->dX2, g->dK2};
+                      g->dX2, g->dK2, g->dLi, g->dRows};
     for (double *p : ptrs)
         if (p) hipFree(p);
+    if (g->dRowsCounter) hipFree(g->dRowsCounter);
+    if (g->hRowsOut) hipHostFree(g->hRowsOut);
     if (g->dInfo) hipFree(g->dInfo);
     if (g->dRedI) hipFree(g->dRedI);
     for (signed char *p : {g->dLr, g->dSr, g->dRr, g->dRm, g->dWr})
@@ -385,6 +387,8 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "lauum_panels")) {
         g->lauum_panels = (int)value;
         g->wi_valid = false;
+        g->li_valid = false;
+        g->w_in_t2 = false;
     } else if (!strcmp(name, "side_alpha")) {
         g->side_alpha = (int)value;
     } else if (!strcmp(name, "pair_panels")) {
@@ -495,6 +499,8 @@ extern "C" int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N,
     g->fitted = false;
     g->fmin_valid = false;
     g->wi_valid = false;
+    g->li_valid = false;
+    g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;
     g->predicted = false;
@@ -521,6 +527,8 @@ extern "C" int gp_set_gower(gp_t *g, int enable, const int *is_discrete, const d
     g->fitted = false;
     g->fmin_valid = false;
     g->wi_valid = false;
+    g->li_valid = false;
+    g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;
     g->predicted = false;
@@ -542,6 +550,8 @@ extern "C" int gp_set_params(gp_t *g, int kernel, int ard, double variance, cons
     g->fitted = false;
     g->fmin_valid = false;
     g->wi_valid = false;
+    g->li_valid = false;
+    g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;
     g->predicted = false;
@@ -640,6 +650,8 @@ extern "C" int gp_kernel_matrix(gp_t *g, double *K) {
                        hipMemcpyDeviceToHost));
     g->fitted = false;  // dA was overwritten
     g->wi_valid = false;
+    g->li_valid = false;
+    g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;
     g->predicted = false;

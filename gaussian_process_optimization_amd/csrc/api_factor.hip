@@ -393,6 +393,8 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     g->fitted = false;
     g->fmin_valid = false;
     g->wi_valid = false;
+    g->li_valid = false;
+    g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;
     g->predicted = false;
@@ -497,6 +499,7 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
             int rcl = wi_lauum(g);
             if (rcl) return rcl;
             g->wi_valid = true;
+            g->w_in_t2 = true;   // dT2 = L^-T of this factor: ensure_linv transposes it instead of solving again
         }
     }
 

@@ -7,9 +7,11 @@
 // 8e: every member factors its own replica, concurrently), the table cut into contiguous row blocks, one per member, and
 // the per-block winners exchanged and merged with NumPy's lowest-index tie rule.  Inside, one worker thread per DISTINCT
 // device drives that device's members through the same entry points a rank of the one-process-per-GPU layout calls
-// (gp_fit, gp_acq_argbest / gp_acq_topk, gp_comm_allgather_best / _topk), so both layouts run the same code.
-//   * devices all different: the members get the communicators of ncclCommInitAll and the winners travel by RCCL all-gather
-//     over xGMI, every member ends up with all pairs (member 0's copy is merged);
+// (gp_fit, gp_acq_argbest / gp_acq_topk), so both layouts run the same scoring code.
+//   * devices all different: the members get the communicators of ncclCommInitAll and the winners travel by ONE grouped RCCL
+//     all-gather over xGMI, enqueued for every member by the calling thread (group_allgather below); every member ends up
+//     with all pairs (member 0's copy is merged).  NOT yet run on more than one device: no multi-GPU box has been available to
+//     any round of this build (include/gphip.h says so too); the host-merge form is what the tests exercise;
 //   * a device listed twice (a one-GPU box rehearsing the N > 1 logic): no communicator can hold one device twice, the pairs
 //     are merged on the host instead -- said by gp_group_info.
 #include "api_internal.h"
@@ -249,18 +251,82 @@ extern "C" int gp_group_acq_argbest(gp_group_t *grp, int type, double par, doubl
     return exchange_and_merge_best(grp, v, ix, sense, idx, val);
 }
 
+// The group's one collective, issued for ALL members from the calling thread inside ncclGroupStart / ncclGroupEnd: k records
+// {double value, int64 global row} per member, every member receives all n k.  Every member is validated and has its record on
+// the device BEFORE the first ncclAllGather is enqueued, so no member can be left waiting in a collective that a failed peer never
+// joined (the earlier form -- one worker thread per device each calling gp_comm_allgather_* -- had that hang path).  If the
+// grouped enqueue itself fails, the communicators are aborted and the group falls back to the host merge for good.
+static int group_allgather(gp_group *grp, int k, const std::vector<double> &v, const std::vector<int64_t> &ix,
+                           std::vector<double> &gv, std::vector<int64_t> &gi) {
+    const int n = (int)grp->m.size();
+    const size_t nd = 2 * (size_t)k;                       // doubles per member
+    for (int i = 0; i < n; ++i) {
+        gp_ctx *g = grp->m[i];
+        if (g->dead) return fail(GP_ERR_STATE, "member %d: the library was shut down (gp_shutdown)", i);
+        if (!g->comm) return fail(GP_ERR_STATE, "member %d holds no communicator", i);
+    }
+    std::vector<std::vector<double>> rec(n, std::vector<double>(nd)), out(n, std::vector<double>(nd * n));
+    for (int i = 0; i < n; ++i) {
+        gp_ctx *g = grp->m[i];
+        HIPCHK(hipSetDevice(g->device));
+        int rc;
+        if ((rc = dev_realloc(&g->dComm, &g->capComm, 2L * GP_TOPK_MAX * (1 + 128)))) return rc;
+        for (int j = 0; j < k; ++j) {
+            rec[i][2 * j] = v[(size_t)i * k + j];
+            memcpy(&rec[i][2 * j + 1], &ix[(size_t)i * k + j], 8);
+        }
+        HIPCHK(hipMemcpyAsync(g->dComm, rec[i].data(), sizeof(double) * nd, hipMemcpyHostToDevice, g->s));
+    }
+    ncclResult_t bad = ncclSuccess;
+    ncclGroupStart();
+    for (int i = 0; i < n; ++i) {
+        gp_ctx *g = grp->m[i];
+        ncclResult_t r = ncclAllGather(g->dComm, g->dComm + 2 * GP_TOPK_MAX, nd, ncclDouble, g->comm, g->s);
+        if (r != ncclSuccess && bad == ncclSuccess) bad = r;
+    }
+    ncclResult_t rend = ncclGroupEnd();
+    if (bad == ncclSuccess) bad = rend;
+    if (bad != ncclSuccess) {
+        for (gp_ctx *g : grp->m) {   // nothing may stay half-enqueued: abort every communicator, host merge from now on
+            if (g->comm) ncclCommAbort(g->comm);
+            g->comm = nullptr;
+            g->nranks = 1;
+        }
+        grp->rccl = false;
+        grp->rccl_note = std::string("grouped ncclAllGather -> ") + ncclGetErrorString(bad) + ": communicators aborted, host merge";
+        return fail(GP_ERR_RCCL, "%s", grp->rccl_note.c_str());
+    }
+    int first = 0;
+    for (int i = 0; i < n; ++i) {   // every member is drained even when an earlier one reported an error
+        gp_ctx *g = grp->m[i];
+        hipError_t e = hipSetDevice(g->device);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(out[i].data(), g->dComm + 2 * GP_TOPK_MAX, sizeof(double) * nd * n, hipMemcpyDeviceToHost, g->s);
+        hipError_t es = hipStreamSynchronize(g->s);
+        if (e == hipSuccess) e = es;
+        if (e != hipSuccess && !first) first = fail(GP_ERR_HIP, "member %d: gather -> %s", i, hipGetErrorString(e));
+    }
+    if (first) return first;
+    gv.resize((size_t)n * n * k);
+    gi.resize((size_t)n * n * k);
+    for (int i = 0; i < n; ++i)
+        for (size_t r = 0; r < (size_t)n * k; ++r) {
+            gv[(size_t)i * n * k + r] = out[i][2 * r];
+            memcpy(&gi[(size_t)i * n * k + r], &out[i][2 * r + 1], 8);
+        }
+    return 0;
+}
+
 // Shared tail of the arg-best entry points: every member has its (value, global row) pair -- exchange (RCCL when the members hold
 // communicators) and merge.
 static int exchange_and_merge_best(gp_group *grp, std::vector<double> &v, std::vector<int64_t> &ix, int sense, int64_t *idx,
                                    double *val) {
     const int n = (int)grp->m.size();
     if (grp->rccl) {
-        std::vector<double> gv((size_t)n * n);
-        std::vector<int64_t> gi((size_t)n * n);
-        // (the collective starts only once EVERY member has its pair: a member that failed would leave the others waiting)
-        int rc = for_members(grp, [&](int i) {
-            return gp_comm_allgather_best(grp->m[i], v[i], ix[i], &gv[(size_t)i * n], &gi[(size_t)i * n]);
-        });
+        std::vector<double> gv;
+        std::vector<int64_t> gi;
+        // (the collective starts only once EVERY member has its pair, and is enqueued for all of them by this one thread)
+        int rc = group_allgather(grp, 1, v, ix, gv, gi);
         if (rc) return rc;
         // every member holds all pairs now; member 0's copy is merged (the others must equal it)
         for (int i = 1; i < n; ++i)
@@ -329,8 +395,8 @@ extern "C" int gp_group_acq_topk(gp_group_t *grp, int type, double par, double f
     const double empty = sense > 0 ? -INFINITY : INFINITY;
     std::vector<double> v((size_t)n * k, empty);
     std::vector<int64_t> ix((size_t)n * k, -1);
-    std::vector<double> gv((size_t)n * n * k);
-    std::vector<int64_t> gi((size_t)n * n * k);
+    std::vector<double> gv;
+    std::vector<int64_t> gi;
     int rc = for_members(grp, [&](int i) {
         if (grp->hi[i] == grp->lo[i]) return 0;
         int64_t *ii = &ix[(size_t)i * k];
@@ -342,11 +408,11 @@ extern "C" int gp_group_acq_topk(gp_group_t *grp, int type, double par, double f
     });
     if (rc) return rc;
     if (grp->rccl) {
-        rc = for_members(grp, [&](int i) {
-            return gp_comm_allgather_topk(grp->m[i], k, &v[(size_t)i * k], &ix[(size_t)i * k], &gv[(size_t)i * n * k],
-                                          &gi[(size_t)i * n * k]);
-        });
-        if (rc) return rc;
+        if ((rc = group_allgather(grp, k, v, ix, gv, gi))) return rc;
+        for (int i = 1; i < n; ++i)
+            if (memcmp(&gv[(size_t)i * n * k], &gv[0], sizeof(double) * n * k) ||
+                memcmp(&gi[(size_t)i * n * k], &gi[0], sizeof(int64_t) * n * k))
+                return fail(GP_ERR_RCCL, "members disagree on the gathered pairs");
         v.assign(gv.begin(), gv.begin() + (size_t)n * k);
         ix.assign(gi.begin(), gi.begin() + (size_t)n * k);
     }

@@ -108,6 +108,18 @@ struct gp_ctx {
     bool wi_valid = false;
     double *dT2 = nullptr;   // solved candidate rows S = K(Xs,X) L^-T (the running right-hand side stays in dT)
     long capT2 = 0;
+    bool w_in_t2 = false;    // dT2 still holds W = L^-T of the current factor (ensure_linv / ensure_wi)
+    // the explicit inverse factor and the scratch of the fused one-row path (onerow.hip, api_rows.hip)
+    double *dLi = nullptr;   // L^-1, lower triangular, Npad x Npad row-major, zeros above the diagonal
+    long capLi = 0;
+    bool li_valid = false;
+    double *dRows = nullptr; // RowsWork partials
+    long capRows = 0;
+    unsigned int *dRowsCounter = nullptr;
+    double *hRowsOut = nullptr;          // pinned, device-visible result block of the fused path
+    std::vector<double> lp_cache;        // local-penalisation batch as last uploaded (Xb | r | s), skipped when unchanged
+    int lp_cache_nb = -1;
+    long rows_fused_calls = 0, rows_fallback_calls = 0;
     double *dLp = nullptr;   // local-penalisation batch (centres, radii, scales)
     double *dX2 = nullptr, *dK2 = nullptr;  // gp_cross_kernel_matrix: second input set and K(X, X2)
     long capX2 = 0, capK2 = 0;
@@ -290,6 +302,7 @@ int run_acq_lp(gp_ctx *g, int type, double par, double fmin, double y_mean, doub
 int wi_lauum(gp_ctx *g);
 int wi_rns(gp_ctx *g);
 int ensure_wi(gp_ctx *g);
+int ensure_linv(gp_ctx *g);
 int lml_grad_impl(gp_ctx *g, double *dvariance, double *dlengthscale, double *dnoise, bool reset_phases);
 int ensure_grad_buffers(gp_ctx *g, long elemsBeta, long M);
 int run_predict_grad(gp_ctx *g);

@@ -30,6 +30,7 @@ int run_predict(gp_ctx *g, int include_noise, bool tiles_only) {
     if ((rc = ensure_panel_inv(g))) return rc;
     if ((rc = dev_realloc(&g->dT, &g->capT, mc_max * Npad))) return rc;
     if ((rc = dev_realloc(&g->dT2, &g->capT2, mc_max * Npad))) return rc;
+    g->w_in_t2 = false;   // dT2 takes the solved candidate rows
     if (M <= g->small_m && !tiles_only) {
         // A handful of rows (the acquisition optimiser's one-row calls): the solve as matrix-vector work bound by ONE read of
         // L (smallm.hip) instead of ~45 dependent tile launches; always true fp64.
@@ -177,6 +178,7 @@ extern "C" int gp_acq_argbest(gp_t *g, int type, double par, double fmin, double
 // the batch centres, radii and scales of the penaliser (<= 256 rows) in a small device buffer of their own
 int upload_lp_batch(gp_ctx *g, const double *Xb, int nb, const double *r0, const double *s0, LpBatch *b) {
     if (nb < 0 || nb > 256) return fail(GP_ERR_ARG, "batch size out of range (0..256)");
+    g->lp_cache_nb = -1;   // (api_rows.hip keeps the last batch it uploaded; this upload replaces it)
     int rc;
     if ((rc = dev_realloc(&g->dLp, &g->capLp, (long)256 * (GP_MAX_D + 2)))) return rc;
     b->X = g->dLp;

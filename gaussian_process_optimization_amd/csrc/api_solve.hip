@@ -162,13 +162,48 @@ int ensure_wi(gp_ctx *g) {
         ++g->emu_fallbacks;   // non-finite factor: the true-fp64 path below returns what the reference would
         g->nphases = 0;
     }
-    int ph = phase_begin(g, "potri_solve", (double)g->N * g->N * g->N / 3.0, 0.0);
-    launch_set_identity(s, T, Npad, Npad);
-    solve_rows(g, T, g->dT2, nt, 1);  // dT2 = L^-T (block upper triangular)
-    phase_end(g, ph);
+    if (g->li_valid && !g->w_in_t2) {
+        // the inverse factor of this fit is at hand (ensure_linv, the fused one-row path): L^-T is its transpose, N^2 traffic
+        // instead of the N^3 / 3 solve
+        int ph = phase_begin(g, "potri_transpose", 0.0, 16.0 * (double)g->N * g->N / 2);
+        launch_transpose_tri(s, g->dT2, g->dLi, Npad, 1);
+        phase_end(g, ph);
+    } else if (!g->w_in_t2) {
+        int ph = phase_begin(g, "potri_solve", (double)g->N * g->N * g->N / 3.0, 0.0);
+        launch_set_identity(s, T, Npad, Npad);
+        solve_rows(g, T, g->dT2, nt, 1);  // dT2 = L^-T (block upper triangular)
+        phase_end(g, ph);
+    }
+    g->w_in_t2 = true;
     if ((rc = wi_lauum(g))) return rc;
     g->wi_valid = true;
     g->predicted = false;  // dT was reused
+    return 0;
+}
+
+// ---- the explicit inverse factor Li = L^-1 (dtrtri, linalg.py:217-227) for the fused one-row path (onerow.hip) -------------------
+// The same solve of the identity as Ky^-1 starts with, kept: lower triangular, row-major, exact zeros above the diagonal.  Half of
+// the potri-equivalent's work (no W W^T product) -- all the acquisition optimiser's gradient calls need between two fits.
+int ensure_linv(gp_ctx *g) {
+    if (g->li_valid) return 0;
+    if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+    const long Npad = g->Npad;
+    const int nt = (int)(Npad / GP_TILE);
+    int rc;
+    if ((rc = ensure_panel_inv(g))) return rc;
+    if ((rc = dev_realloc(&g->dT, &g->capT, Npad * Npad))) return rc;
+    if ((rc = dev_realloc(&g->dT2, &g->capT2, Npad * Npad))) return rc;
+    if ((rc = dev_realloc(&g->dLi, &g->capLi, Npad * Npad))) return rc;
+    if (!g->w_in_t2) {
+        int ph = phase_begin(g, "potri_solve", (double)g->N * g->N * g->N / 3.0, 0.0);
+        launch_set_identity(g->s, g->dT, Npad, Npad);
+        solve_rows(g, g->dT, g->dT2, nt, 1);  // dT2 = L^-T (true fp64 in either arithmetic mode)
+        phase_end(g, ph);
+        g->w_in_t2 = true;
+        g->predicted = false;  // dT was reused
+    }
+    launch_transpose_tri(g->s, g->dLi, g->dT2, Npad, 0);
+    g->li_valid = true;
     return 0;
 }
 

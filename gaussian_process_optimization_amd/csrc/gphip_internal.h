@@ -65,6 +65,27 @@ __device__ __forceinline__ double gp_exp_nonpos(double x) {
     return ldexp(p, (int)n);
 }
 
+// the stationary covariance as a function of r^2, and with it g(r) = dK_dr(r) / r (finite at r = 0 for both kernels):
+// RBF.K_of_r / dK_dr (rbf.py:50-54), Matern52.K_of_r / dK_dr (stationary.py:575-579)
+__device__ __forceinline__ double gp_k_of_r2(int kernel, double variance, double r2) {
+    if (kernel == 0) return variance * gp_exp_nonpos(-0.5 * r2);
+    const double s5 = 2.23606797749978969640917366873128;  // sqrt(5)
+    const double r = sqrt(r2);
+    return variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * gp_exp_nonpos(-s5 * r);
+}
+__device__ __forceinline__ void gp_k_and_g(int kernel, double variance, double r2, double &k, double &g) {
+    if (kernel == 0) {
+        k = variance * gp_exp_nonpos(-0.5 * r2);
+        g = -k;  // dK_dr = -r k
+    } else {
+        const double s5 = 2.23606797749978969640917366873128;
+        const double r = sqrt(r2);
+        const double e = gp_exp_nonpos(-s5 * r);
+        k = variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * e;
+        g = -(5.0 / 3.0) * variance * (1.0 + s5 * r) * e;  // (10/3 r - 5 r - 5 sqrt5/3 r^2) e / r
+    }
+}
+
 // divisor used when staging inputs for a covariance evaluation
 __host__ __device__ static inline double kp_div(const KernParams &kp, int d) { return kp.gower ? kp.gdiv[d] : kp.ls[d]; }
 
@@ -165,6 +186,34 @@ void launch_small_forward_solve(hipStream_t s, const double *L, long lda, const 
 // beta[m, :] = Kx[m, :] Wi for m < M (Wi symmetric, Npad x Npad)
 void launch_small_wi_product(hipStream_t s, const double *Wi, long ldw, long Npad, const double *Kx, long ldk, int M,
                              double *beta, long ldb);
+
+// ---- onerow.hip: the acquisition optimiser's one-row calls as three launches over the explicit inverse factor ------------------
+#define ROWS_MAX_M 4       // locations per pass of the fused path
+#define ROWS_MAX_XS 128    // ... with M * D <= ROWS_MAX_XS doubles travelling in the kernel arguments
+struct RowsX {
+    int M;
+    double xs[ROWS_MAX_XS];   // [M][D] row-major, as the caller gave them
+};
+struct RowsAcq {
+    int on;                   // 0: posterior only
+    int type;                 // GP_ACQ_*
+    double par, fmin, y_mean, y_std;
+    int lp, transform, nb;    // local penalisation (LP.py): on / log transform / batch size
+    const double *Xb, *r0, *s0;
+};
+struct RowsWork {             // device scratch (api_rows.hip sizes it): every partial has one writer
+    double *wpart, *bpart, *meanpart, *vpart, *gpart;
+    unsigned int *counter;
+};
+long rows_tiles(int nt);
+int rows_block_height(int nt);   // rows of the tile per workgroup: 32 for matrices of a few tiles, else 128
+size_t rows_gpart_elems(long N);
+// results (host-visible block of 3 MV (1 + D) doubles, MV = 1 for M = 1 else ROWS_MAX_M):
+//   [mean MV][var MV][acq MV][dmdx MV D][dvdx MV D][dacq MV D]
+void launch_rows(hipStream_t s, const double *Li, long Npad, const RowsX &rx, const KernParams &kp, const double *X, long N,
+                 const double *alpha, int want_grad, double kss, double noise_add, const RowsAcq &aq, const RowsWork &w,
+                 double *out);
+void launch_transpose_tri(hipStream_t s, double *dst, const double *src, long n, int mode);
 
 // ---- grad.hip ---------------------------------------------------------------------------------
 #define GP_GRAD_CH 16

@@ -15,6 +15,7 @@
 // reads Ky^-1 once, and produces all D+2 sums; per-tile partials are reduced in fixed order.
 #include "gphip_internal.h"
 #include "../../include/gphip.h"
+#include "acq_math.h"
 
 #define GCH 16  // ARD dimensions handled per pass (accumulators stay in registers)
 
@@ -24,19 +25,7 @@ __device__ __forceinline__ double wave_sum_g(double v) {
     return v;
 }
 
-// k(r) and g(r) = dK_dr(r) / r (finite at r = 0 for both kernels)
-__device__ __forceinline__ void k_and_g(int kernel, double variance, double r2, double &k, double &g) {
-    if (kernel == 0) {
-        k = variance * gp_exp_nonpos(-0.5 * r2);
-        g = -k;  // dK_dr = -r k
-    } else {
-        const double s5 = 2.23606797749978969640917366873128;
-        const double r = sqrt(r2);
-        const double e = gp_exp_nonpos(-s5 * r);
-        k = variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * e;
-        g = -(5.0 / 3.0) * variance * (1.0 + s5 * r) * e;  // (10/3 r - 5 r - 5 sqrt5/3 r^2) e / r
-    }
-}
+#define k_and_g gp_k_and_g   // gphip_internal.h
 
 // ---- identity / symmetrise ----------------------------------------------------------------------
 __global__ void set_identity_kernel(double *T, long ld, long n) {
@@ -290,31 +279,8 @@ __global__ void acq_grad_kernel(int type, double par, double fmin, double y_mean
                                 double *dout) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-    const double m = mean[i] * y_std + y_mean;
-    double v = var[i] * (y_std * y_std);
-    v = (v < 1e-10) ? 1e-10 : v;
-    double s = sqrt(v);
-    const double ds_scale = (y_std * y_std) / (2.0 * s);  // dsdx = dvdx / (2 sqrt(v)), gpmodel.py:140
-    double f, c_m, c_s;                                    // df = c_m * dmdx + c_s * dsdx
-    if (type == GP_ACQ_LCB) {
-        f = -m + par * s;
-        c_m = -1.0;
-        c_s = par;
-    } else {
-        if (s < 1e-10) s = 1e-10;
-        const double u = (fmin - m - par) / s;
-        const double phi = exp(-0.5 * u * u) / 2.50662827463100050241576528481105;
-        const double Phi = 0.5 * erfc(-u / 1.41421356237309504880168872420970);
-        if (type == GP_ACQ_EI) {
-            f = s * (u * Phi + phi);
-            c_m = -Phi;
-            c_s = phi;
-        } else {
-            f = Phi;
-            c_m = -(phi / s);
-            c_s = -(phi / s) * u;
-        }
-    }
+    double f, c_m, c_s, ds_scale;                          // df = c_m * dmdx + c_s * dsdx (acq_math.h)
+    acq_terms(type, par, fmin, y_mean, y_std, mean[i], var[i], f, c_m, c_s, ds_scale);
     out[i] = -f;
     for (int d = 0; d < D; ++d) {
         const double dm = dmdx[i * D + d] * y_std;
@@ -397,47 +363,12 @@ void launch_transpose_blocks(hipStream_t s, double *dst, const double *src, long
 }
 
 // ---- local-penalisation epilogue (GPyOpt/GPyOpt/acquisitions/LP.py:40-110) -----------------------------
-// scipy.stats.norm.logcdf == cephes log_ndtr: log(ndtr(z)) for z > -20, the asymptotic series below it,
-// -ndtr(-z) above 6.
-__device__ __forceinline__ double log_ndtr(double z) {
-    if (z > 6.0) return -0.5 * erfc(z / 1.41421356237309504880168872420970);
-    if (z > -20.0) return log(0.5 * erfc(-z / 1.41421356237309504880168872420970));
-    const double log_lhs = -0.5 * z * z - log(-z) - 0.5 * log(2.0 * 3.14159265358979323846);
-    double last_total = 0.0, right_hand_side = 1.0, numerator = 1.0, denom_factor = 1.0;
-    const double denom_cons = 1.0 / (z * z);
-    long sign = 1, i = 0;
-    while (fabs(last_total - right_hand_side) > 2.220446049250313e-16) {
-        i += 1;
-        last_total = right_hand_side;
-        sign = -sign;
-        denom_factor *= denom_cons;
-        numerator *= (double)(2 * i - 1);
-        right_hand_side += (double)sign * numerator * denom_factor;
-        if (i > 200) break;
-    }
-    return log_lhs + log(right_hand_side);
-}
-// in: negacq[M] = -acq(x) (gp_acq output).  out[M] = -log-transformed acq - sum_k logcdf((|x - x0_k| - r_k)/s_k)
-// transform: 0 = none (log(acq + 1e-50)), 1 = softplus (LP.py:77-83)
+// in: negacq[M] = -acq(x) (gp_acq output).  out[M] = -log-transformed acq - sum_k logcdf((|x - x0_k| - r_k)/s_k)  (acq_math.h)
 __global__ void lp_kernel(const double *negacq, const double *Xs, long M, int D, const double *Xb, int nb,
                           const double *r0, const double *s0, int transform, double *out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-    double f = -negacq[i];
-    if (transform == 1)
-        f = (f >= 40.0) ? log(f) : log(log1p(exp(f)));
-    else
-        f = log(f + 1e-50);
-    f = -f;
-    for (int k = 0; k < nb; ++k) {
-        double d2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-            const double df = Xs[i * D + d] - Xb[k * D + d];
-            d2 = fma(df, df, d2);
-        }
-        f -= log_ndtr((sqrt(d2) - r0[k]) / s0[k]);
-    }
-    out[i] = f;
+    out[i] = lp_value(negacq[i], Xs + i * D, D, Xb, nb, r0, s0, transform);
 }
 void launch_lp(hipStream_t s, const double *negacq, const double *Xs, long M, int D, const double *Xb, int nb,
                const double *r0, const double *s0, int transform, double *out) {
@@ -445,38 +376,12 @@ void launch_lp(hipStream_t s, const double *negacq, const double *Xs, long M, in
                        transform, out);
 }
 // value and gradient of the penalised acquisition (LP.py:112-140).  in: negacq[M] = -acq(x), dneg[M, D] = -d acq / dx (the
-// outputs of acq_grad_kernel), overwritten in place by the penalised value and its gradient.  The penaliser's gradient is
-// the reference's: one scalar per (candidate, centre) summed over the batch and subtracted from every dimension.
+// outputs of acq_grad_kernel), overwritten in place by the penalised value and its gradient (acq_math.h).
 __global__ void lp_grad_kernel(double *negacq, double *dneg, const double *Xs, long M, int D, const double *Xb, int nb,
                                const double *r0, const double *s0, int transform) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-    const double a = -negacq[i];
-    double f, scale;
-    if (transform == 1) {
-        const double sp = log1p(exp(a));
-        f = (a >= 40.0) ? log(a) : log(sp);
-        scale = 1.0 / (sp * (1.0 + exp(-a)));
-    } else {
-        f = log(a + 1e-50);
-        scale = 1.0 / a;
-    }
-    f = -f;
-    double pen = 0.0;
-    for (int k = 0; k < nb; ++k) {
-        double d2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-            const double df = Xs[i * D + d] - Xb[k * D + d];
-            d2 = fma(df, df, d2);
-        }
-        const double nm = sqrt(d2);
-        const double z = (nm - r0[k]) / s0[k];
-        f -= log_ndtr(z);
-        const double cdf = 0.5 * erfc(-z / 1.41421356237309504880168872420970);
-        if (!(cdf < 1e-50)) pen += 1.0 / (s0[k] * 2.50662827463100050241576528481105 * cdf) * exp(-0.5 * z * z) / nm;
-    }
-    negacq[i] = f;
-    for (int d = 0; d < D; ++d) dneg[i * D + d] = scale * dneg[i * D + d] - pen;
+    negacq[i] = lp_value_grad(negacq[i], dneg + i * D, Xs + i * D, D, Xb, nb, r0, s0, transform);
 }
 void launch_lp_grad(hipStream_t s, double *negacq, double *dneg, const double *Xs, long M, int D, const double *Xb, int nb,
                     const double *r0, const double *s0, int transform) {

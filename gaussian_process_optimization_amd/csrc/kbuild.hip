@@ -15,15 +15,7 @@
 // 8 N^2 / 2 written (lower tiles only).
 #include "gphip_internal.h"
 
-__device__ __forceinline__ double k_of_r2(int kernel, double variance, double r2) {
-    if (kernel == 0) {
-        return variance * gp_exp_nonpos(-0.5 * r2);
-    } else {
-        const double s5 = 2.23606797749978969640917366873128;  // sqrt(5)
-        const double r = sqrt(r2);
-        return variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * gp_exp_nonpos(-s5 * r);
-    }
-}
+#define k_of_r2 gp_k_of_r2   // gphip_internal.h
 // one 1-D factor of the Gower product kernel: K_of_r(|dx|) for a continuous dimension (dx already divided by
 // the variable's range), K_of_r(dx != 0) for a discrete one (stationary.py:122-129)
 __device__ __forceinline__ double gower_factor(int kernel, double variance, double dx, int disc) {

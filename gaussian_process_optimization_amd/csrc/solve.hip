@@ -203,12 +203,7 @@ void launch_predict_reduce(hipStream_t s, const double *T, long ldt, long M, lon
 }
 
 // ---- posterior mean at the training inputs (GPModel.get_fmin, gpmodel.py:125-129) --------------
-__device__ __forceinline__ double k_of_r2_s(int kernel, double variance, double r2) {
-    if (kernel == 0) return variance * gp_exp_nonpos(-0.5 * r2);
-    const double s5 = 2.23606797749978969640917366873128;
-    const double r = sqrt(r2);
-    return variance * (1.0 + s5 * r + (5.0 / 3.0) * r2) * gp_exp_nonpos(-s5 * r);
-}
+#define k_of_r2_s gp_k_of_r2   // gphip_internal.h
 #define TM_SPLIT 8
 // grid (N/128 row tiles, TM_SPLIT column slices); part[slice][i]
 __global__ __launch_bounds__(256) void train_mean_kernel(const double *X, long N, KernParams kp, const double *alpha,

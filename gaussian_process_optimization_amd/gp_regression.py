@@ -261,6 +261,19 @@ class GPRegression(Parameterized):
         self._h.set_candidates(Xnew)
         return Xnew
 
+    def _few_rows(self, Xnew, limit=8):
+        """``Xnew`` as a 2-D float array when it is a handful of locations of a fitted single-output model -- the calls an
+        optimiser makes one location at a time: they go down as ONE gp_predict_rows call, locations by value -- else None."""
+        Xnew = np.asarray(Xnew, dtype=float)
+        if Xnew.ndim == 1:
+            Xnew = Xnew[None, :]
+        if self.output_dim != 1 or not (1 <= Xnew.shape[0] <= limit):
+            return None
+        if Xnew.shape[1] != self.input_dim:
+            raise ValueError("candidates have %d columns, model has %d" % (Xnew.shape[1], self.input_dim))
+        self._ensure_fit()
+        return Xnew
+
     def _empty(self, Xnew, full_cov):
         """Zero prediction locations: the shapes NumPy gives the reference (posterior.py:273-302 on a (0, D) array)."""
         Xnew = np.asarray(Xnew, dtype=float)
@@ -275,6 +288,9 @@ class GPRegression(Parameterized):
         e = self._empty(Xnew, full_cov)
         if e is not None:
             return e
+        few = None if full_cov else self._few_rows(Xnew)
+        if few is not None:
+            return self._h.predict_rows(few, include_noise=False)
         self._stage(Xnew, fit=full_cov)
         if full_cov:
             return self._h.predict_full_cov(include_noise=False)
@@ -287,11 +303,15 @@ class GPRegression(Parameterized):
         e = self._empty(Xnew, full_cov)
         if e is not None:
             return e
-        self._stage(Xnew, fit=full_cov)
-        if full_cov:
-            mean, var = self._h.predict_full_cov(include_noise=include_likelihood)
+        few = None if full_cov else self._few_rows(Xnew)
+        if few is not None:
+            mean, var = self._h.predict_rows(few, include_noise=include_likelihood)
         else:
-            mean, var = self._predict_resident(include_likelihood)
+            self._stage(Xnew, fit=full_cov)
+            if full_cov:
+                mean, var = self._h.predict_full_cov(include_noise=include_likelihood)
+            else:
+                mean, var = self._predict_resident(include_likelihood)
         if self.normalizer is not None:
             mean = self.normalizer.inverse_mean(mean)
             if full_cov and mean.shape[1] > 1:
@@ -324,6 +344,9 @@ class GPRegression(Parameterized):
         Xn = np.asarray(Xnew, dtype=float)
         if Xn.ndim == 2 and Xn.shape[0] == 0:
             return np.empty((0, self.input_dim, self.output_dim)), np.empty((0, self.input_dim))
+        few = self._few_rows(Xnew)
+        if few is not None:
+            return self._h.predict_rows(few, grad=True)[2:]
         self._stage(Xnew)
         return self._h.predict_grad()
 

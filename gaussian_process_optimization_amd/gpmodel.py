@@ -111,9 +111,15 @@ class GPModel(BOModel):
         un-normalised mean / variance."""
         X = np.atleast_2d(X)
         gp = self.model
-        mean, var = gp.predict(X)
+        few = gp._few_rows(X)
+        if few is not None:     # posterior and gradients of a handful of locations in ONE device call (gp_predict_rows)
+            mean, var, jac_mean, jac_var = gp._h.predict_rows(few, include_noise=True, grad=True)
+            if gp.normalizer is not None:
+                mean, var = gp.normalizer.inverse_mean(mean), gp.normalizer.inverse_variance(var)
+        else:
+            mean, var = gp.predict(X)
+            jac_mean, jac_var = gp.predictive_gradients(X)
         std = np.sqrt(np.maximum(var, _VAR_FLOOR))
-        jac_mean, jac_var = gp.predictive_gradients(X)
         jac_mean = jac_mean[..., 0]
         if gp.normalizer is not None:
             jac_mean = jac_mean * gp.normalizer.std

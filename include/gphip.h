@@ -211,6 +211,28 @@ int gp_acq_lp_argbest(gp_t *gp, int type, double par, double fmin, double y_mean
                       const double *Xb, int nb, const double *r_x0, const double *s_x0, int sense,
                       const int64_t *exclude, int nex, int64_t *idx, double *val);
 
+/* ---- a handful of locations per call: the acquisition optimiser's inner loop --------------------------------
+ * scipy's L-BFGS-B evaluates the acquisition ONE location per call, hundreds of times between two fits
+ * (GPyOpt/GPyOpt/optimization/optimizer.py:36-61 -> acquisitions/base.py:33-50, LP.py:105-140 -> models/gpmodel.py:95-142
+ * -> GPy/GPy/core/gp.py:297-354,407-454).  These two entry points are gp_set_candidates followed by the batched calls
+ * named below, as ONE call taking the locations Xs[M, D] by value; for M <= option "small_m" (8) locations of a
+ * single-output model with M D <= 128 they run as three launches over the explicit inverse factor L^-1 (dtrtri,
+ * linalg.py:217-227; built once per fit, half the work of Ky^-1) with no copy commands (csrc/onerow.hip), otherwise
+ * through the batched calls themselves.  Same results either way (tests/test_gpu_rows.py); the resident candidate block
+ * of gp_set_candidates is unspecified afterwards.
+ *
+ * gp_predict_rows = gp_predict(include_noise, mean[M], var[M]) and, when dmdx / dvdx are given (both or neither),
+ *                   gp_predict_grad(dmdx[M, D], dvdx[M, D]).  mean / var may be NULL.  P = 1 layouts.
+ * gp_acq_rows     = gp_acq / gp_acq_grad (lp = 0) or gp_acq_lp / gp_acq_lp_grad (lp = 1, with transform, Xb, nb, r_x0,
+ *                   s_x0 as there): out[M], and dout[M, D] when given. */
+int gp_predict_rows(gp_t *gp, const double *Xs, int64_t M, int include_noise, double *mean, double *var, double *dmdx,
+                    double *dvdx);
+int gp_acq_rows(gp_t *gp, const double *Xs, int64_t M, int type, double par, double fmin, double y_mean, double y_std,
+                int lp, int transform, const double *Xb, int nb, const double *r_x0, const double *s_x0, double *out,
+                double *dout);
+/* how many of those calls took the fused path / the batched calls since gp_create (route checks of the tests) */
+int gp_rows_stats(gp_t *gp, int64_t *fused, int64_t *fallback);
+
 /* ---- multi-GPU (one process per GPU; RCCL over xGMI) ---------------------
  * The candidate table shards across ranks; every rank holds a replica of the
  * fitted model.  uid is ncclUniqueId (128 bytes) produced on rank 0 and carried
@@ -244,9 +266,13 @@ int gp_comm_selftest_fit_record(const double *root_state, double *state_out, int
  * the fit does not shard, every member factors its replica, the devices side by side), the table cut into contiguous row
  * blocks -- member i of n takes rows [i M/n .., first M % n members one row longer] -- and the per-block winners merged with
  * NumPy's lowest-index tie rule.  With all devices different the members hold the communicators of ncclCommInitAll and
- * the winners travel by RCCL all-gather over xGMI (the same gp_comm_allgather_best / _topk a rank of the
- * one-process-per-GPU layout calls); with a device listed more than once (a one-GPU box rehearsing the logic) the pairs
- * are merged on the host, which gp_group_info reports.  Calls are synchronous; one group per caller thread. */
+ * the winners travel by ONE grouped RCCL all-gather over xGMI, enqueued for every member by the calling thread inside
+ * ncclGroupStart / ncclGroupEnd after every member has been validated (no member can wait on a peer that never joined; a
+ * failed enqueue aborts the communicators and the group merges on the host from then on); with a device listed more than
+ * once (a one-GPU box rehearsing the logic) the pairs are merged on the host, which gp_group_info reports.
+ * STATUS: the RCCL route has not run on more than one device in any record of this repository -- no multi-GPU box was
+ * available to the builder; what the tests execute is the host-merge route (devices = {0, 0, ...}) and the
+ * single-member communicator.  Calls are synchronous; one group per caller thread. */
 typedef struct gp_group gp_group_t;
 int gp_group_create(gp_group_t **out, int ndev, const int *devices);
 int gp_group_destroy(gp_group_t *grp);

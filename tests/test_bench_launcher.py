@@ -6,6 +6,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -178,3 +180,52 @@ def test_rendezvous_under_torch_distributed_run(tmp_path):
     for r in recs:
         assert r["uid"] and r["torch"] is False and r["port"] == str(port)
         assert [x[0] for x in r["recs"]] == [0, 1] and r["recs"][0][1] == r["recs"][1][1]   # one parent: the agent
+
+
+def test_default_workload_is_one_job_at_every_rank_count():
+    """`bench.py --gpus N`: the SAME candidate table as the N = 1 run, split into contiguous row blocks that cover it exactly
+    once (strong scaling: value = job iterations/s, not multiplied by the rank count)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    try:
+        import bench
+    finally:
+        sys.path.pop(0)
+    _, _, table1 = bench.synthetic(64, 8, 10000, cand_seed=1236)
+    for world in (1, 2, 3, 4, 8):
+        blocks, seen = [], 0
+        for rank in range(world):
+            lo, hi = bench.shard_bounds(10000, rank, world)
+            assert lo == seen and hi > lo
+            seen = hi
+            blocks.append(bench.synthetic(64, 8, 10000, cand_seed=1236)[2][lo:hi])
+        assert seen == 10000 and np.array_equal(np.vstack(blocks), table1)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'scaling, value = "strong", job_rate' in src and "world * job_rate" not in src
+
+
+def test_rendezvous_place_is_private(tmp_path, monkeypatch):
+    """The control channel's socket sits in a directory only this user can enter: the launcher's own mkdtemp directory with
+    its random key, or -- under torch.distributed.run -- a per-user 0700 directory that is refused when anybody else can
+    enter it."""
+    sys.path.insert(0, ROOT)
+    try:
+        import bench
+    finally:
+        sys.path.pop(0)
+    d = tmp_path / "priv"
+    d.mkdir(mode=0o700)
+    monkeypatch.setenv("GPHIP_BENCH_RDV_DIR", str(d))
+    monkeypatch.setenv("GPHIP_BENCH_RDV_KEY", "k" * 32)
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    key, path = bench.rendezvous_place()
+    assert key == b"k" * 32 and os.path.dirname(path) == str(d) and "29512" in os.path.basename(path)
+    os.chmod(d, 0o755)
+    with pytest.raises(RuntimeError, match="private"):
+        bench.rendezvous_place()
+    monkeypatch.delenv("GPHIP_BENCH_RDV_DIR")
+    monkeypatch.delenv("GPHIP_BENCH_RDV_KEY")
+    monkeypatch.setattr(bench.tempfile, "gettempdir", lambda: str(tmp_path))
+    key2, path2 = bench.rendezvous_place()
+    st = os.stat(os.path.dirname(path2))
+    assert st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0 and len(key2) == 64

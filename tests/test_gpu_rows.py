@@ -1,0 +1,236 @@
+"""GPU: the one-call entry points for a handful of locations (gp_predict_rows / gp_acq_rows, csrc/onerow.hip + api_rows.hip)
+against the batched entry points they stand for and against the oracle.
+
+What scipy's L-BFGS-B issues between two fits (GPyOpt/GPyOpt/optimization/optimizer.py:36-61 -> acquisitions/base.py:33-50,
+LP.py:105-140 -> models/gpmodel.py:95-142 -> GPy/GPy/core/gp.py:297-354,407-454).  The fused path works from the explicit
+inverse factor L^-1 where the batched path substitutes against L: same quantities, other rounding -- held to 1e-9 of each
+other on well-conditioned models and to the north-star 1e-6 of the oracle everywhere, including the hardest spot for an
+explicit inverse: the variance ON training points at noise 1e-6 (var ~ 2e-6 next to kss = 1).
+"""
+import numpy as np
+import pytest
+
+import gaussian_process_optimization_amd as gpo
+from gaussian_process_optimization_amd import _lib
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+ACQS = ((_lib.GP_ACQ_EI, 0.01), (_lib.GP_ACQ_LCB, 2.0), (_lib.GP_ACQ_MPI, 0.01))
+
+
+def _close(a, b, rel):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert a.shape == b.shape
+    assert np.max(np.abs(a - b)) <= rel * max(np.max(np.abs(b)), 1e-300), float(np.max(np.abs(a - b)))
+
+
+def _fitted(N, D, kernel, ard, noise, seed):
+    X, Y, Xs = O.synthetic_problem(N, D, 40, seed=seed)
+    ls = O.default_lengthscale(D, ard)
+    h = _lib.Handle(0)
+    h.set_option("emulate_fp64", 0)
+    h.set_data(X, Y)
+    h.set_params(kernel, int(ard), 1.1, ls, noise)
+    h.fit()
+    return h, X, Y, Xs, ls
+
+
+@pytest.mark.parametrize("N,D,kernel,ard", [(100, 2, _lib.GP_KERNEL_RBF, False), (512, 8, _lib.GP_KERNEL_RBF, False),
+                                            (1100, 3, _lib.GP_KERNEL_MATERN52, True), (2200, 5, _lib.GP_KERNEL_MATERN52, False),
+                                            (4500, 16, _lib.GP_KERNEL_RBF, True)])
+@pytest.mark.parametrize("noise", [1e-2, 1e-6])
+def test_rows_calls_equal_the_batched_calls(N, D, kernel, ard, noise):
+    """gp_predict_rows / gp_acq_rows for M = 1 .. 8 (fused: one pass for M <= 4, two beyond) and M = 9 (the batched calls
+    inside) against gp_set_candidates + gp_predict / gp_predict_grad / gp_acq_grad / gp_acq_lp_grad.  Sizes cover one row
+    block (N = 100), exactly one chunk, two chunks with a cut last one (N = 1100: 9 row blocks), and 36 row blocks."""
+    h, X, Y, Xs, ls = _fitted(N, D, kernel, ard, noise, seed=N)
+    Xs = Xs.copy()
+    Xs[1] = X[3]                    # ON a training point: r = 0, the variance's worst case
+    Xs[6] = X[N - 1]
+    fmin = h.fmin()
+    rel = 1e-9 if noise >= 1e-4 else 2e-6       # two float64 routes on cond(Ky) ~ 1e8: each within 1e-6 of the truth
+    Xb = Xs[20:23]
+    r0, s0 = np.array([0.05, 0.2, 0.01]), np.array([0.03, 0.1, 0.02])
+    before = h.rows_stats()
+    cancel = np.abs(h.alpha()).sum() * 1.1 / np.min(ls)
+    vscale = 1.1 / np.min(ls)
+    for M in (1, 2, 4, 5, 8, 9):
+        x = Xs[:M]
+        h.set_candidates(x)
+        mu_b, var_b = h.predict(True)
+        _, var0_b = h.predict(False)
+        dm_b, dv_b = h.predict_grad()
+        mu, var, dm, dv = h.predict_rows(x, True, grad=True)
+        mu0, var0 = h.predict_rows(x, False)
+        _close(mu, mu_b, rel)
+        _close(mu0, mu_b, rel)
+        # gradients_X sums N terms g(r) alpha_n (x - x_n) / l^2 that cancel: two summation orders agree to eps * sum |terms|
+        assert np.max(np.abs(dm - dm_b)) <= rel * np.max(np.abs(dm_b)) + 1e-13 * cancel
+        # d var / dx sums g(r) (-2 beta_n) (x - x_n) / l^2 with beta = Ky^-1 k* (entries ~ 1 / noise): on the natural scale
+        # variance / lengthscale the two routes agree far inside the north-star 1e-6
+        assert np.max(np.abs(dv - dv_b)) <= max(rel, 1e-8) * np.max(np.abs(dv_b)) + (1e-12 if noise >= 1e-4 else 1e-8) * vscale
+        # variances relative to themselves (they span 1e-6 .. 1): the north-star tolerance element by element
+        assert np.max(np.abs(var - var_b) / np.abs(var_b)) <= max(rel, 1e-9) * (1 if noise >= 1e-4 else 1)
+        assert np.max(np.abs(var0 - var0_b)) <= 1e-6 * np.max(np.abs(var_b))
+        for t, par in ACQS:
+            for shift, scale in ((0.0, 1.0), (3.5, 2.0)):
+                a_b, da_b = h.acq_grad(t, par, fmin, shift, scale)
+                a, da = h.acq_rows(x, t, par, fmin, shift, scale, grad=True)
+                a_only = h.acq_rows(x, t, par, fmin, shift, scale)
+                _close(a, a_b, max(rel, 1e-8))
+                _close(a_only, a, max(rel, 1e-8))    # |w|^2 summed per row block (gradient call) or per row (value call)
+                _close(da, da_b, 1e-6 if noise < 1e-4 else 1e-7)
+            tr = 1 if t == _lib.GP_ACQ_LCB else 0
+            v_b, dvl_b = h.acq_lp_grad(t, par, fmin, tr, Xb=Xb, r_x0=r0, s_x0=s0)
+            v, dvl = h.acq_rows(x, t, par, fmin, grad=True, lp=(tr, Xb, r0, s0))
+            v_only = h.acq_rows(x, t, par, fmin, lp=(tr, Xb, r0, s0))
+            ok = np.isfinite(v_b)
+            assert np.array_equal(np.isfinite(v), ok)
+            _close(v_only[ok], v[ok], 1e-6)
+            _close(v[ok], v_b[ok], 1e-6)
+            okg = np.isfinite(dvl_b)
+            assert np.array_equal(np.isfinite(dvl), okg)
+            if okg.any():
+                _close(dvl[okg], dvl_b[okg], 1e-5)
+            v0 = h.acq_rows(x, t, par, fmin, lp=(tr, None, None, None))        # no batch yet: the log transform alone
+            h.set_candidates(x)
+            _close(v0[np.isfinite(v0)], h.acq_lp(t, par, fmin, tr)[np.isfinite(v0)], 1e-6)
+    after = h.rows_stats()
+    assert after["fused"] > before["fused"] and after["fallback"] > before["fallback"]      # M = 9 took the batched calls
+    h.close()
+
+
+@pytest.mark.parametrize("kname", ["rbf", "Mat52"])
+@pytest.mark.parametrize("noise", [1e-2, 1e-6])
+def test_rows_calls_against_the_oracle(kname, noise):
+    """One location at a time, as L-BFGS issues them, against GPModel.predict_withGradients / acquisition_function_with
+    Gradients restated (oracle): mean, sd, both gradients, EI / LCB / MPI with a normaliser, on and off training points."""
+    N, D = 700, 4
+    X, Y, Xs = O.synthetic_problem(N, D, 12, seed=5)
+    Xs = np.vstack([Xs[:6], X[[0, 17, N - 1]], X[[5]] + 1e-5])   # (closer than ~1e-8 the reference's Gram-trick distance is noise)
+    ls = O.default_lengthscale(D, False)
+    cls = gpo.kern.RBF if kname == "rbf" else gpo.kern.Matern52
+    gm = gpo.GPModel(kernel=cls(D, 1.2, ls), noise_var=noise, max_iters=0, verbose=False)
+    gm.updateModel(X, Y, None, None)
+    gp0 = O.OracleGP(X, Y, O.make_kernel(kname, D, 1.2, ls), noise)
+    gm0 = O.OracleGPModel(gp0)
+    f0 = gm0.get_fmin()
+    assert abs(gm.get_fmin() - f0) <= 1e-6 * max(1.0, abs(f0))
+    pairs = ((gpo.AcquisitionEI(gm), lambda x: O.acq_EI_withGradients(gm0, x, 0.01, f0)),
+             (gpo.AcquisitionLCB(gm), lambda x: O.acq_LCB_withGradients(gm0, x, 2.0)),
+             (gpo.AcquisitionMPI(gm), lambda x: O.acq_MPI_withGradients(gm0, x, 0.01, f0)))
+    tol = 1e-6
+    vscale = 1.2 / ls[0]            # natural scale of d var / dx: variance / lengthscale (as test_gpu_parity.py's stress cases)
+    h = gm.model._h
+    worst = {"fused": 0.0, "batched": 0.0}
+    for x in Xs:
+        x = x[None, :]
+        m, s, dm, ds = gm.predict_withGradients(x)
+        m0, s0, dm0, ds0 = gm0.predict_withGradients(x)
+        assert abs(m.item() - m0.item()) <= tol * max(1.0, abs(m0.item()))
+        assert abs(s.item() - s0.item()) <= tol * s0.item() + 1e-12
+        np.testing.assert_allclose(dm, dm0, rtol=0, atol=tol * max(np.max(np.abs(dm0)), 1e-3))
+        # d sd / dx = d var / dx / (2 sd): compared as d var / dx on its own scale (sd reaches 1e-3 on training points)
+        np.testing.assert_allclose(ds * 2 * s, ds0 * 2 * s0, rtol=0, atol=tol * vscale)
+        h.set_candidates(x)
+        dv_batched = h.predict_grad()[1]
+        worst["fused"] = max(worst["fused"], float(np.max(np.abs(ds * 2 * s - ds0 * 2 * s0))) / vscale)
+        worst["batched"] = max(worst["batched"], float(np.max(np.abs(dv_batched - ds0 * 2 * s0))) / vscale)
+        mu1, sd1 = gm.predict(x)
+        assert abs(mu1.item() - m0.item()) <= tol * max(1.0, abs(m0.item())) and abs(sd1.item() - s0.item()) <= tol * s0.item() + 1e-12
+        for acq, ref in pairs:
+            a, da = acq.acquisition_function_withGradients(x)
+            a0, da0 = ref(x)
+            if noise >= 1e-4:      # at noise 1e-6 EI / MPI sit many sigma out in the tail (test_gpu_parity.py measures that)
+                assert abs(a.item() + a0.item()) <= 1e-5 * max(abs(a0.item()), 1e-12), (type(acq).__name__, a, a0)
+                np.testing.assert_allclose(da, -da0, rtol=0, atol=1e-5 * max(np.max(np.abs(da0)), 1e-12))
+            _close(acq.acquisition_function(x), a, 1e-6)
+    # the explicit inverse factor is not further from the reference's LAPACK result than the substitution route is
+    assert worst["fused"] <= max(4 * worst["batched"], 1e-9), worst
+    assert gm.model._h.rows_stats()["fused"] > 0
+    gm.model.close()
+
+
+def test_rows_route_state_and_errors():
+    """The inverse factor is built once per fit and dropped with it; Ky^-1 asked for afterwards comes from its transpose
+    (no second solve) and equals the one built the usual way; option small_m = 0 turns the fused path off; argument
+    errors are reported, not executed."""
+    h, X, Y, Xs, ls = _fitted(900, 3, _lib.GP_KERNEL_RBF, False, 1e-2, seed=2)
+    Wi_ref = h.woodbury_inv().copy()
+    h.fit()                                           # drops Ky^-1 and the inverse factor
+    h.profile(True)
+    mu, var, dm, dv = h.predict_rows(Xs[:1], True, grad=True)
+    assert [p["name"] for p in h.phases()] == ["rows_fused_grad"]
+    Wi = h.woodbury_inv()                             # L^-T still sits where the inverse factor's build left it: product only
+    assert [p["name"] for p in h.phases()] == ["rows_fused_grad", "potri_lauum"] and np.array_equal(Wi, Wi_ref)
+    h.fit()
+    h.predict_rows(Xs[:1], True, grad=True)
+    h.set_candidates(Xs[:20])
+    h.predict(True)                                   # the batched solve takes that buffer over
+    Wi = h.woodbury_inv()                             # ... so L^-T comes back as the transpose of the kept inverse factor
+    assert "potri_transpose" in [p["name"] for p in h.phases()] and "potri_solve" not in [p["name"] for p in h.phases()]
+    assert np.array_equal(Wi, Wi_ref)
+    h.profile(False)
+    # a new fit with other hyper-parameters: the rows calls follow it
+    h.set_params(_lib.GP_KERNEL_RBF, 0, 0.7, ls * 1.3, 1e-2)
+    h.fit()
+    mu2, var2 = h.predict_rows(Xs[:1], True)
+    h.set_candidates(Xs[:1])
+    mu_b, var_b = h.predict(True)
+    _close(mu2, mu_b, 1e-9)
+    _close(var2, var_b, 1e-9)
+    assert abs(mu2.item() - mu.item()) > 1e-6
+    st = h.rows_stats()
+    h.set_option("small_m", 0)
+    mu3, var3 = h.predict_rows(Xs[:1], True)
+    _close(mu3, mu_b, 1e-9)                           # (the batched calls inside, tile path with small_m = 0)
+    _close(var3, var_b, 1e-9)
+    assert h.rows_stats()["fallback"] == st["fallback"] + 1 and h.rows_stats()["fused"] == st["fused"]
+    h.set_option("small_m", 8)
+    with pytest.raises((ValueError, RuntimeError), match="M < 1"):
+        _lib.check(h.lib, h.lib.gp_predict_rows(h.h, Xs.ctypes.data, 0, 1, None, None, None, None), "gp_predict_rows")
+    with pytest.raises((ValueError, RuntimeError), match="go together"):
+        dm1 = np.empty((1, 3))
+        _lib.check(h.lib, h.lib.gp_predict_rows(h.h, Xs.ctypes.data, 1, 1, None, None, dm1.ctypes.data, None), "gp_predict_rows")
+    with pytest.raises((ValueError, RuntimeError), match="unknown acquisition"):
+        h.acq_rows(Xs[:1], 7, 0.0, 0.0)
+    # bitwise repeatable (every partial sum has one writer and a fixed order)
+    a1 = h.acq_rows(Xs[:3], _lib.GP_ACQ_EI, 0.01, -1.0, grad=True)
+    a2 = h.acq_rows(Xs[:3], _lib.GP_ACQ_EI, 0.01, -1.0, grad=True)
+    assert np.array_equal(a1[0], a2[0]) and np.array_equal(a1[1], a2[1])
+    h.close()
+
+
+def test_rows_calls_under_the_gower_kernel():
+    """The fork's pairing on the fused path: Gower k* (stationary.py:116-135) in mean / variance / beta, Euclidean gradients_X on
+    the kernel's own lengthscale around them (stationary.py:336-364) -- one location at a time against the batched calls and
+    the oracle."""
+    dom = [{'name': 'a', 'type': 'discrete', 'domain': (0, 1, 2, 3)}, {'name': 'x', 'type': 'continuous', 'domain': (-2.0, 5.0)},
+           {'name': 'b', 'type': 'discrete', 'domain': (10, 20)}, {'name': 'y', 'type': 'continuous', 'domain': (0.0, 0.5)}]
+    space0 = O.MixedSpace(dom)
+    rng = np.random.default_rng(3)
+    X, Xs = space0.draw(rng, 300), space0.draw(rng, 10)
+    Xs[0] = X[7]
+    Y = O.normalize((np.sin(X[:, 1]) + 0.3 * X[:, 0] - 0.1 * (X[:, 2] == 20) + 2 * X[:, 3])[:, None])
+    space = gpo.Design_space(dom)
+    gm = gpo.GPModel(kernel=gpo.kern.Matern52(4, 0.9, 1.7, Gower=True, space=space), noise_var=1e-3, max_iters=0, Gower=True,
+                     space=space, verbose=False)
+    gm.updateModel(X, Y, None, None)
+    gm0 = O.OracleGPModel(O.OracleGP(X, Y, O.make_kernel("Mat52", 4, 0.9, [1.7], Gower=True, space=space0), 1e-3))
+    h = gm.model._h
+    for i in range(10):
+        x = Xs[i:i + 1]
+        m, s, dm, ds = gm.predict_withGradients(x)
+        m0, s0, dm0, ds0 = gm0.predict_withGradients(x)
+        np.testing.assert_allclose(m, m0, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(s, s0, rtol=1e-6)
+        np.testing.assert_allclose(dm, dm0, rtol=0, atol=1e-6 * np.max(np.abs(dm0)))
+        np.testing.assert_allclose(ds, ds0, rtol=0, atol=1e-6 * np.max(np.abs(ds0)))
+        h.set_candidates(x)
+        dm_b, dv_b = h.predict_grad()
+        dm_r, dv_r = h.predict_rows(x, grad=True)[2:]
+        _close(dm_r, dm_b, 1e-9)
+        _close(dv_r, dv_b, 1e-8)
+    assert h.rows_stats()["fused"] >= 20
+    gm.model.close()

@@ -843,7 +843,7 @@ def main():
                          "avg_launch_ms": gs["ms"] / max(gs["launches"], 1),
                          "flops_per_launch_avg": gs["flops"] / max(gs["launches"], 1),
                          "launch_filter": "every launch of that kernel symbol in the timed region (launches of >= 1400 output "
-                                          "tiles: trailing updates, candidate updates; > 90 % of the flops), %.0f per step"
+                                          "tiles: trailing updates, candidate updates; > 90 %% of the flops), %.0f per step"
                                           % (gs["launches"] / max(args.steps, 1)),
                          # the same symbol with no launch of its own kind beside it: gp_fit then gp_predict, 3 un-timed passes
                          "separate_calls_reference": None if sep is None else {

@@ -4,6 +4,13 @@
 
 thread_local std::string g_err;
 
+// first failed launch / stream operation of the calling thread since the last report (gphip_internal.h)
+static thread_local bool g_note_set = false;
+static thread_local std::string g_note_msg;
+
+// Every error return of the library goes through here.  A launch failure noted earlier in the SAME call (GP_LAUNCH / GP_NOTE)
+// that this return would otherwise leave behind -- the entry point is leaving before its GP_SYNC -- is folded into the message
+// and cleared: it must not surface as the failure of the thread's next, unrelated call.
 int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -11,12 +18,13 @@ int fail(int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_err = buf;
+    if (g_note_set) {
+        g_err += " [after: " + g_note_msg + "]";
+        g_note_set = false;
+    }
     return code;
 }
 
-// first failed launch / stream operation of the calling thread since the last report (gphip_internal.h)
-static thread_local bool g_note_set = false;
-static thread_local std::string g_note_msg;
 void gp_note_hip(hipError_t e, const char *what, const char *file, int line) {
     if (e == hipSuccess || g_note_set) return;
     char buf[512];
@@ -29,6 +37,9 @@ int gp_pending_error() {
     g_note_set = false;
     return fail(GP_ERR_HIP, "%s", g_note_msg.c_str());
 }
+// A note that survived its call after all (an entry point that returned success without synchronising) is dropped when the next
+// entry point starts: GP_DEAD_CHECK, the first thing every gp_* function does with its context.
+void gp_clear_stale_note() { g_note_set = false; }
 
 static std::mutex g_ds_mu;
 static std::map<int, DevStreams> g_ds;

@@ -210,7 +210,9 @@ int factor_lookahead(gp_ctx *g, const PredPipe &pp) {
             long keep = g->own_keep_base + (long)g->own_keep_per_row * n * W / 6;
             // (one-call entry points: once the candidate stages share the bulk stream's CUs the trailing update lasts longer and the
             // chain waits again; the bulk stream then keeps own_keep_pipe_pct % of the rule's share)
-            if (pp.on && J >= pred_start) keep = keep * g->own_keep_pipe_pct / 100;
+            // (never at the FIRST panel that owns columns: there own_prev is still its initial nt, and keep = 0 would hand the
+            // whole trailing update to the chain stream -- pipe_start_pct = 0, or so few panels that pred_start rounds to 0)
+            if (pp.on && J >= pred_start && own_prev < nt) keep = keep * g->own_keep_pipe_pct / 100;
             long t_own = n * (n + 1) / 2 + n - keep;
             int c = 0;
             while (c < own_prev && (long)(c + 1) * (c + 2) / 2 + (c + 1) <= t_own) ++c;

@@ -45,8 +45,10 @@ int gp_pending_error();
         if (e_ != hipSuccess) return fail(GP_ERR_HIP, "hipStreamSynchronize(%s) -> %s (%s:%d)", #stream, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 #define GP_ERR_RANGE (-1000)   // internal: an operand of the residue path left the fixed-point range (the caller repeats in fp64)
+void gp_clear_stale_note();
 #define GP_DEAD_CHECK(g)                                                                            \
     do {                                                                                            \
+        gp_clear_stale_note();                                                                      \
         if ((g)->dead)                                                                              \
             return fail(GP_ERR_STATE, "the library was shut down (gp_shutdown): destroy this context and create a new one"); \
     } while (0)

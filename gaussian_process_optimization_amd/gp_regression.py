@@ -103,6 +103,7 @@ class GPRegression(Parameterized):
         if not isinstance(kernel, Stationary):
             raise TypeError("kernel must be kern.RBF or kern.Matern52")
         self.kern = kernel
+        self.kern._device = int(device)     # kern.K evaluates on the owning model's device (kern.py, _scratch_handle)
         self.likelihood = Gaussian(variance=noise_var)
         self.Gaussian_noise = self.likelihood
         self.link_parameters(self.kern, self.likelihood)

@@ -49,11 +49,9 @@ class Stationary(Parameterized):
     def K(self, X, X2=None):
         """kern.K(X[, X2]) -- stationary.py:107-140, evaluated by the K-build kernels (kern.py:119 is the contract:
         X2 None -> K(X, X) with the diagonal forced to the variance, X2 given -> the [N, M2] cross covariance)."""
-        # one context per kernel object, kept: a loop over kern.K (the kernel contract's caller) does not pay a context's
-        # creation and tear-down per call
-        h = self.__dict__.get("_kh")
-        if h is None or h.h is None:
-            h = self.__dict__["_kh"] = _lib.Handle(0)
+        # one scratch context per DEVICE for the whole process (not per kernel object: a kernel holds hyper-parameters only,
+        # so it deep-copies and pickles like the reference's; a loop over kern.K still pays no context creation per call)
+        h = _scratch_handle(int(getattr(self, "_device", 0)))
         X = _lib.as_f64(X, 2)
         h.set_data(X, np.zeros((X.shape[0], 1)))
         h.set_params(self._kernel_id, self.ARD, float(self.variance), self.lengthscale.values, 0.0)
@@ -61,9 +59,10 @@ class Stationary(Parameterized):
             h.set_gower(*gower_config(self.space, self.input_dim))
         else:
             h.set_gower()
-        if X2 is None:
-            return h.kernel_matrix()
-        return h.cross_kernel_matrix(X2)
+        out = h.kernel_matrix() if X2 is None else h.cross_kernel_matrix(X2)
+        if X.shape[0] > _SCRATCH_KEEP_N:      # an N x N device buffer of gigabytes is not kept alive behind the caller's back
+            release_scratch(int(getattr(self, "_device", 0)))
+        return out
 
     def Kdiag(self, X):
         ret = np.empty(X.shape[0])  # stationary.py:195-198
@@ -73,6 +72,25 @@ class Stationary(Parameterized):
     def copy(self):
         return self.__class__(self.input_dim, float(self.variance), self.lengthscale.values.copy(), self.ARD,
                               Gower=self.Gower, space=self.space)
+
+
+_SCRATCH = {}
+_SCRATCH_KEEP_N = 4096        # scratch contexts that served more rows than this are closed right after the call (128 MB at 4096)
+
+
+def _scratch_handle(device=0):
+    h = _SCRATCH.get(device)
+    if h is None or h.h is None:
+        h = _SCRATCH[device] = _lib.Handle(device)
+    return h
+
+
+def release_scratch(device=None):
+    """Close the scratch context(s) ``kern.K`` evaluates on (all devices, or one)."""
+    for d in ([device] if device is not None else list(_SCRATCH)):
+        h = _SCRATCH.pop(d, None)
+        if h is not None:
+            h.close()
 
 
 def gower_config(space, input_dim):

@@ -206,9 +206,9 @@ def test_optimize_on_a_flat_ridge_ends_at_the_same_likelihood(monkeypatch, mode,
 def test_bench_starts_its_own_ranks_on_one_device():
     """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command): the parent spawns two fresh rank
     processes, they rendezvous over 127.0.0.1 and print ONE JSON line from rank 0 that holds BOTH multi-rank measurements (reduced
-    here: N = 2048): the metric's own workload with every rank scoring its own candidates and an arg-best exchange per step
-    (weak scaling: the series the driver's N = 1, 2, 4, 8 runs form), and the candidate-sharding configuration C4 -- ONE table of
-    20 000 candidates split over the ranks, winner compared with rank 0's single-GPU pass over the whole table.  Both ranks sit on
+    here: N = 2048): the metric's own workload as ONE job -- the table of the N = 1 run split over the ranks, an arg-best exchange per
+    step, value = job iterations/s (strong scaling), the winner the N = 1 run finds -- and the candidate-sharding configuration C4 --
+    ONE table of 20 000 candidates split over the ranks, winner compared with rank 0's single-GPU pass over the whole table.  Both ranks sit on
     device 0 here (GPHIP_BENCH_SAME_DEVICE: a one-GPU box), where RCCL refuses the duplicate device and the pairs travel over the
     ranks' control channel (labelled so); on an 8-GPU node the only difference is the device index."""
     import json
@@ -226,13 +226,22 @@ def test_bench_starts_its_own_ranks_on_one_device():
     assert out.stdout.strip() == lines[0].strip()        # nothing else on stdout: librccl's banner is sent to stderr
     d = json.loads(lines[0])
     cfg = d["config"]
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"
     assert d["metric"].startswith("GP fit+predict iters/sec") and cfg["workload"].startswith("C3")
-    assert cfg["candidates_per_gpu"] == 3000 and abs(d["value"] - 2 * cfg["job_iters_per_s"]) < 1e-9 * d["value"]
+    assert cfg["candidates_total"] == 3000 and cfg["candidates_this_rank"] == 1500
+    assert abs(d["value"] - cfg["job_iters_per_s"]) < 1e-9 * d["value"]       # the job's rate, NOT multiplied by the rank count
+    assert abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-6 * 1e3
     assert "launch_ranks" in cfg["launcher"]
     assert cfg["ranks_agree_on_winner"] is True
     assert {r["rank"] for r in cfg["rank_records"]} == {0, 1}
-    assert 0 <= cfg["best_candidate_global_row"] < 6000                       # a row of the 2 x 3000 table
+    # the same table as a one-rank run: the same winner, bit for bit
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--N", "2048", "--M", "3000", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-emulated-line"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert d1["scaling"] == "strong" and d1["config"]["candidates_this_rank"] == 3000
+    assert cfg["best_candidate_global_row"] == d1["config"]["best_candidate_global_row"]
+    assert cfg["best_value"] == d1["config"]["best_value"]
     assert cfg["collective"].startswith("host sockets") or cfg["rccl_comm_ranks"] == 2
     c4 = d["c4_sharded"]
     assert c4["scaling"] == "strong" and c4["workload"].startswith("C4")

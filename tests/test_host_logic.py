@@ -246,3 +246,18 @@ def test_group_merges_follow_numpy_tie_rules():
         pi, pv = merge_topk(kv, ki, k, sense)
         assert list(pi) == list(full) and list(tv[:full.size]) == list(scores[full])
     assert lib.gp_merge_best(0, None, None, 1, None, None) == _lib.GP_ERR_ARG
+
+
+def test_kernel_objects_deepcopy_and_pickle_like_the_reference():
+    """A kernel holds hyper-parameters only (the scratch context kern.K evaluates on is per device, module level): it
+    deep-copies and pickles, as GPy's kernels do, and the copy is independent of the original."""
+    import copy
+    import pickle
+    import gaussian_process_optimization_amd as gpo
+    k = gpo.kern.Matern52(3, 1.3, [0.2, 0.3, 0.4], ARD=True)
+    for twin in (copy.deepcopy(k), pickle.loads(pickle.dumps(k)), k.copy()):
+        assert type(twin) is type(k) and twin.ARD and float(twin.variance) == 1.3
+        assert np.array_equal(twin.lengthscale.values, [0.2, 0.3, 0.4])
+        twin.variance[:] = 2.0
+        assert float(k.variance) == 1.3
+    assert "_kh" not in k.__dict__

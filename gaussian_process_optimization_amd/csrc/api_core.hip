@@ -446,6 +446,9 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "debug_potrf_lds")) {
         if (value < 0 || value > (1 << 20)) return fail(GP_ERR_ARG, "debug_potrf_lds out of range");
         potrf_set_debug_lds((int)value);   // process-wide test hook: forces refused diagonal-tile launches (tests/test_gpu_round4.py)
+    } else if (!strcmp(name, "rows_nt")) {
+        if (value < -1 || value > 1) return fail(GP_ERR_ARG, "rows_nt out of range (-1: automatic, 0, 1)");
+        g->rows_nt = (int)value;
     } else if (!strcmp(name, "small_m")) {
         if (value < 0 || value > 8) return fail(GP_ERR_ARG, "small_m out of range (0..8)");
         g->small_m = value;

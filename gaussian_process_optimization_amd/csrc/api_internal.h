@@ -122,6 +122,9 @@ struct gp_ctx {
     std::vector<double> lp_cache;        // local-penalisation batch as last uploaded (Xb | r | s), skipped when unchanged
     int lp_cache_nb = -1;
     long rows_fused_calls = 0, rows_fallback_calls = 0;
+    int rows_nt = -1;                    // fused one-row path: non-temporal loads of the inverse factor (option "rows_nt"; -1: when its
+                                         // lower triangle exceeds the 256 MiB Infinity Cache, N > 8192 -- measured -10 % at N = 16384,
+                                         // +10 % at N = 4096 where the next call finds the factor cached: profiles/r05_small_calls.txt)
     double *dLp = nullptr;   // local-penalisation batch (centres, radii, scales)
     double *dX2 = nullptr, *dK2 = nullptr;  // gp_cross_kernel_matrix: second input set and K(X, X2)
     long capX2 = 0, capK2 = 0;

@@ -79,7 +79,7 @@ static int rows_fused(gp_ctx *g, const double *Xs, int M, int include_noise, int
                                      (want_grad ? 2.0 : 1.0) * 8.0 * (double)g->N * g->N / 2)
                        : -1;
         launch_rows(g->s, g->dLi, g->Npad, rx, g->kp, g->dX, g->N, g->dAlpha, want_grad, g->kp.variance,
-                    include_noise ? g->noise : 0.0, aq, w, g->hRowsOut);
+                    include_noise ? g->noise : 0.0, aq, w, g->hRowsOut, g->rows_nt < 0 ? (g->Npad > 8192 ? 1 : 0) : g->rows_nt);
         if (timed) phase_end(g, ph);
         GP_SYNC(g->s);
         const double *o = g->hRowsOut;

@@ -212,7 +212,7 @@ size_t rows_gpart_elems(long N);
 //   [mean MV][var MV][acq MV][dmdx MV D][dvdx MV D][dacq MV D]
 void launch_rows(hipStream_t s, const double *Li, long Npad, const RowsX &rx, const KernParams &kp, const double *X, long N,
                  const double *alpha, int want_grad, double kss, double noise_add, const RowsAcq &aq, const RowsWork &w,
-                 double *out);
+                 double *out, int nt_loads);
 void launch_transpose_tri(hipStream_t s, double *dst, const double *src, long n, int mode);
 
 // ---- grad.hip ---------------------------------------------------------------------------------

@@ -55,6 +55,13 @@ __device__ __forceinline__ double rw_block_sum(double v, double *sh) {
     return ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
+// one 16-byte load of the inverse factor; NT: marked non-temporal (the factor is read once per pass and is far larger than the caches)
+template <bool NT>
+__device__ __forceinline__ double2_t rw_load2(const double *p) {
+    if (NT) return __builtin_nontemporal_load((const double2_t *)p);
+    return *(const double2_t *)p;
+}
+
 // sum of p[i stride] for i = first, first + step, ... < end, added in that order; the loads go out eight at a time (one load
 // after the other, each waiting for its predecessor's add, cost ~1 us apiece: 60 us for 64 partials)
 __device__ __forceinline__ double rw_strided_sum(const double *p, long stride, int first, int step, int end) {
@@ -75,7 +82,7 @@ __device__ __forceinline__ double rw_strided_sum(const double *p, long stride, i
 // ---- forward: wpart[C][m][r] = sum_{k in chunk C} Li[r, k] k*_m[k];  meanpart[C][m] = sum_{k in chunk C} k*_m[k] alpha[k] -----------
 // RB rows of the tile per workgroup (128, or 32 for matrices of a few tiles: four times the workgroups, a quarter of the
 // dependent load -> reduce steps in each -- the launch is latency-bound there, not bandwidth-bound)
-template <int MV, int RB>
+template <int MV, int RB, bool NT>
 __global__ __launch_bounds__(256) void rows_forward_kernel(const double *Li, long ld, RowsX rx, KernParams kp, const double *X, long N,
                                                            const double *alpha, double *wpart, long Npad, int nt,
                                                            double *meanpart) {
@@ -145,8 +152,8 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(const double *Li, lon
         double2_t x0[RW_Q], x1[RW_Q];
 #pragma unroll
         for (int q = 0; q < RW_Q; ++q) {
-            x0[q] = (128 * q < klim) ? *(const double2_t *)(p0 + 128 * q) : zero2;
-            x1[q] = (128 * q < klim) ? *(const double2_t *)(p1 + 128 * q) : zero2;
+            x0[q] = (128 * q < klim) ? rw_load2<NT>(p0 + 128 * q) : zero2;
+            x1[q] = (128 * q < klim) ? rw_load2<NT>(p1 + 128 * q) : zero2;
         }
 #pragma unroll
         for (int m = 0; m < MV; ++m) {
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(const double *Li, lon
 }
 
 // ---- backward: bpart[R][m][k] = sum_{r in block R} Li[r, k] w_m[r];  vpart[R][m] = sum_{r in block R} w_m[r]^2 -------------------------
-template <int MV, int RB>
+template <int MV, int RB, bool NT>
 __global__ __launch_bounds__(256) void rows_backward_kernel(const double *Li, long ld, const double *wpart, long Npad, int M,
                                                             double *bpart, double *vpart) {
     __shared__ double wv[MV][RB];
@@ -212,8 +219,8 @@ __global__ __launch_bounds__(256) void rows_backward_kernel(const double *Li, lo
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const double *p = base + (long)(r + u) * ld;
-            x[u][0] = *(const double2_t *)p;
-            x[u][1] = two ? *(const double2_t *)(p + 128) : zero2;
+            x[u][0] = rw_load2<NT>(p);
+            x[u][1] = two ? rw_load2<NT>(p + 128) : zero2;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -374,35 +381,35 @@ size_t rows_gpart_elems(long N) { return (size_t)((N + 63) / 64) * RW_GROW; }
 
 int rows_block_height(int nt) { return nt <= 16 ? 32 : GP_TILE; }
 
-template <int MV, int RB>
+template <int MV, int RB, bool NT>
 static void launch_rows_t(hipStream_t s, const double *Li, long Npad, const RowsX &rx, const KernParams &kp, const double *X, long N,
                           const double *alpha, int want_grad, double kss, double noise_add, const RowsAcq &aq, const RowsWork &w,
                           double *out) {
     const int nt = (int)(Npad / GP_TILE);
     const unsigned tiles = (unsigned)rows_tiles(nt) * (GP_TILE / RB);
     const unsigned fin = (unsigned)((N + 63) / 64);
-    GP_LAUNCH((rows_forward_kernel<MV, RB>), dim3(tiles), dim3(256), 0, s, Li, Npad, rx, kp, X, N, alpha, w.wpart, Npad, nt, w.meanpart);
+    GP_LAUNCH((rows_forward_kernel<MV, RB, NT>), dim3(tiles), dim3(256), 0, s, Li, Npad, rx, kp, X, N, alpha, w.wpart, Npad, nt, w.meanpart);
     if (want_grad)
-        GP_LAUNCH((rows_backward_kernel<MV, RB>), dim3(tiles), dim3(256), 0, s, Li, Npad, w.wpart, Npad, rx.M, w.bpart, w.vpart);
+        GP_LAUNCH((rows_backward_kernel<MV, RB, NT>), dim3(tiles), dim3(256), 0, s, Li, Npad, w.wpart, Npad, rx.M, w.bpart, w.vpart);
     GP_LAUNCH(rows_finish_kernel<MV>, dim3(fin), dim3(256), 0, s, rx, kp, X, N, alpha, w.wpart, w.bpart, w.meanpart, w.vpart, Npad, nt,
               RB, want_grad, kss, noise_add, aq, w.gpart, w.counter, out);
 }
 
 void launch_rows(hipStream_t s, const double *Li, long Npad, const RowsX &rx, const KernParams &kp, const double *X, long N,
                  const double *alpha, int want_grad, double kss, double noise_add, const RowsAcq &aq, const RowsWork &w,
-                 double *out) {
+                 double *out, int nt_loads) {
     const bool low = rows_block_height((int)(Npad / GP_TILE)) == 32;
+#define RW_GO(MV, RB, NT) launch_rows_t<MV, RB, NT>(s, Li, Npad, rx, kp, X, N, alpha, want_grad, kss, noise_add, aq, w, out)
     if (rx.M == 1) {
-        if (low)
-            launch_rows_t<1, 32>(s, Li, Npad, rx, kp, X, N, alpha, want_grad, kss, noise_add, aq, w, out);
-        else
-            launch_rows_t<1, GP_TILE>(s, Li, Npad, rx, kp, X, N, alpha, want_grad, kss, noise_add, aq, w, out);
+        if (low) RW_GO(1, 32, false);
+        else if (nt_loads) RW_GO(1, GP_TILE, true);
+        else RW_GO(1, GP_TILE, false);
     } else {
-        if (low)
-            launch_rows_t<ROWS_MAX_M, 32>(s, Li, Npad, rx, kp, X, N, alpha, want_grad, kss, noise_add, aq, w, out);
-        else
-            launch_rows_t<ROWS_MAX_M, GP_TILE>(s, Li, Npad, rx, kp, X, N, alpha, want_grad, kss, noise_add, aq, w, out);
+        if (low) RW_GO(ROWS_MAX_M, 32, false);
+        else if (nt_loads) RW_GO(ROWS_MAX_M, GP_TILE, true);
+        else RW_GO(ROWS_MAX_M, GP_TILE, false);
     }
+#undef RW_GO
 }
 
 // ---- Li = (L^-T)^T: lower triangular, explicit zeros above the diagonal; and back -------------------------------------------------------

@@ -11,6 +11,9 @@ rng = np.random.default_rng(1)
 X = rng.uniform(0, 1, (N, D)); Y = rng.standard_normal((N, 1))
 h = _lib.Handle(0)
 h.set_option("emulate_fp64", 0)
+for kv in sys.argv[3:]:
+    k, v = kv.split("=")
+    h.set_option(k, int(v))
 h.set_data(X, Y); h.set_params(0, 0, 1.0, [0.7], 1e-2); h.fit(); fmin = h.fmin()
 Xs = rng.uniform(0, 1, (1, D))
 t0 = time.perf_counter(); h.acq_rows(Xs, 0, 0.01, fmin, grad=True); t_first = time.perf_counter() - t0

@@ -525,8 +525,8 @@ extern "C" int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N,
 // The fork's Gower kernel option (GPy/GPy/kern/src/stationary.py:61-65,116-135; lengthscales = variable ranges,
 // GPyOpt/GPyOpt/core/task/space.py:351-362).  Only K is Gower: Kdiag stays `variance` and the gradient
 // formulas stay Euclidean in the fork.  Both are reproduced for the predictive gradients (gp_predict_grad, gp_acq_grad,
-// gp_acq_lp_grad: Gower K(Xs, X) inside Euclidean gradients_X, see run_predict_grad); the hyper-parameter gradients of a
-// Gower model are refused (gp_lml_grad returns GP_ERR_STATE; the host differentiates the device LML numerically).
+// gp_acq_lp_grad: Gower K(Xs, X) inside Euclidean gradients_X, see run_predict_grad) and for the hyper-parameter gradients
+// (gp_lml_grad: Gower K in the variance gradient, Euclidean dK/dr in the lengthscale gradients, stationary.py:218-238).
 extern "C" int gp_set_gower(gp_t *g, int enable, const int *is_discrete, const double *range) {
     if (!g) return fail(GP_ERR_ARG, "null gp");
     GP_DEAD_CHECK(g);

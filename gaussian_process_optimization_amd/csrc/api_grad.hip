@@ -7,8 +7,8 @@ int lml_grad_impl(gp_ctx *g, double *dvariance, double *dlengthscale, double *dn
     GP_DEAD_CHECK(g);
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
-    if (g->kp.gower) return fail(GP_ERR_STATE, "hyper-gradients of the Gower kernel are not replicated (the fork mixes "
-                                               "Gower K with Euclidean dK/dr, stationary.py:218-238)");
+    // (a Gower model gets the fork's values: K through the Gower branch in the variance gradient, Euclidean dK/dr on the kernel's own
+    // lengthscale in the lengthscale gradients, stationary.py:218-238 -- not derivatives of its LML, which the host layer knows)
     HIPCHK(hipSetDevice(g->device));
     int rc;
     if (reset_phases) g->nphases = 0;
@@ -56,8 +56,6 @@ extern "C" int gp_fit_grad(gp_t *g, int maxtries, double *lml, double *logdet, d
     GP_DEAD_CHECK(g);
     if (!g->have_data || !g->have_params) return fail(GP_ERR_STATE, "set data and params before gp_fit_grad");
     if (g->P > 16) return fail(GP_ERR_ARG, "gp_lml_grad supports P <= 16");
-    if (g->kp.gower) return fail(GP_ERR_STATE, "hyper-gradients of the Gower kernel are not replicated (the fork mixes "
-                                               "Gower K with Euclidean dK/dr, stationary.py:218-238)");
     HIPCHK(hipSetDevice(g->device));
     const int nt = (int)(g->Npad / GP_TILE);
     // emulated: Ky^-1 in residue form after the factorisation (wi_rns) instead of fp64 stages pipelined behind it

@@ -98,6 +98,11 @@ __global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *X, lon
     double *xj = xi + (long)D * GP_TILE;    // [D][128]
     double *ai = xj + (long)D * GP_TILE;    // [P][128]
     double *aj = ai + (long)P * GP_TILE;    // [P][128]
+    // Gower model: the fork's update_gradients_full takes K -- the variance gradient's weight -- through the Gower branch
+    // (stationary.py:224 over :116-135) and everything with dK_dr through the Euclidean distance on the kernel's own lengthscale
+    // (:227-238): a second staging of the inputs, divided by the variables' ranges
+    double *ui = aj + (long)P * GP_TILE;    // [D][128]  (gower only)
+    double *uj = ui + (long)D * GP_TILE;    // [D][128]
     __shared__ double red[4][NACC];
     const int tid = threadIdx.x;
     const long t = blockIdx.x;
@@ -110,6 +115,10 @@ __global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *X, lon
         const long gi = (long)tm * GP_TILE + r, gj = (long)tn * GP_TILE + r;
         xi[d * GP_TILE + r] = (gi < N) ? X[gi * D + d] / kp.ls[d] : 0.0;
         xj[d * GP_TILE + r] = (gj < N) ? X[gj * D + d] / kp.ls[d] : 0.0;
+        if (kp.gower) {
+            ui[d * GP_TILE + r] = (gi < N) ? X[gi * D + d] / kp.gdiv[d] : 0.0;
+            uj[d * GP_TILE + r] = (gj < N) ? X[gj * D + d] / kp.gdiv[d] : 0.0;
+        }
     }
     for (int idx = tid; idx < GP_TILE * P; idx += 256) {
         const int p = idx / GP_TILE, r = idx - p * GP_TILE;
@@ -156,7 +165,16 @@ __global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *X, lon
             double kv, gv;
             k_and_g(kp.kernel, kp.variance, s, kv, gv);
             const bool diag = (gcc == gr);
-            if (diag) kv = kp.variance;  // Kdiag is exactly the variance (stationary.py:162-166, r = 0)
+            if (kp.gower) {              // product of the 1-D factors, diagonal included (variance^D there, as the fork's K has it)
+                kv = 1.0;
+                for (int d = 0; d < D; ++d) {
+                    const double df = ui[d * GP_TILE + r] - uj[d * GP_TILE + c];
+                    const double rr = kp.gdisc[d] ? (df != 0.0 ? 1.0 : 0.0) : fabs(df);
+                    kv *= gp_k_of_r2(kp.kernel, kp.variance, rr * rr);
+                }
+            } else if (diag) {
+                kv = kp.variance;  // Kdiag is exactly the variance (stationary.py:162-166, r = 0)
+            }
             const double w = diag ? 1.0 : 2.0;
             acc[0] = fma(w * kv, dLdK, acc[0]);
             if (diag) acc[1] += dLdK;
@@ -200,7 +218,7 @@ void launch_lml_grad(hipStream_t s, const double *X, long N, long Npad, const Ke
                      const double *alpha, int P, const double *Wi, long ldw, double *partial, double *out) {
     const int nt = (int)(Npad / GP_TILE);
     const long ntile = (long)nt * (nt + 1) / 2;
-    const size_t shm = ((size_t)2 * kp.D * GP_TILE + (size_t)2 * P * GP_TILE) * sizeof(double);
+    const size_t shm = ((size_t)(kp.gower ? 4 : 2) * kp.D * GP_TILE + (size_t)2 * P * GP_TILE) * sizeof(double);
     GP_LAUNCH(lml_grad_tile_kernel, dim3((unsigned)ntile), dim3(256), shm, s, X, N, kp, ard, d0, alpha, Npad,
                        P, Wi, ldw, partial);
     GP_LAUNCH(sum_partials_kernel, dim3(NACC), dim3(1024), 0, s, partial, ntile, NACC, out);

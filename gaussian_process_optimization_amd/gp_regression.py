@@ -115,6 +115,9 @@ class GPRegression(Parameterized):
             self.normalizer = normalizer
         self.Y_metadata = Y_metadata
         self.max_jitter_tries = 5  # jitchol default, linalg.py:56
+        # hyper-parameter search of a Gower model: 'differences' of the device LML (default), or 'fork' = the fork's own
+        # update_gradients_full values (stationary.py:218-238 on a Gower K: not derivatives of the objective)
+        self.gower_gradients = 'differences' 
         self._h = _lib.Handle(device)
         self._groups = {}        # replica groups over several devices, keyed by the device tuple (_device_group)
         self._data_epoch = 0
@@ -229,7 +232,7 @@ class GPRegression(Parameterized):
 
     def _log_likelihood_gradients_natural(self):
         nls = self.kern.lengthscale.size
-        if self._dirty and not self._uses_gower():
+        if self._dirty:
             # objective and gradients of a new parameter vector (every L-BFGS evaluation, core/model.py:96-127):
             # fit and the Ky^-1 solve go down as ONE call, gp_fit_grad (bitwise the results of the two calls)
             self._push_params()
@@ -395,11 +398,12 @@ class GPRegression(Parameterized):
     def _obj_grad(self, x):
         try:
             self.optimizer_array = x
-            if not self._uses_gower():
+            if not self._uses_gower() or self.gower_gradients == 'fork':
                 g = self.objective_function_gradients()   # gp_fit_grad: leaves the LML of this x behind
                 return self.objective_function(), g
             # Gower kernel: the fork pairs the Gower K with Euclidean gradient formulas (stationary.py:218-238), which
-            # are not gradients of this objective; forward differences of the device LML are used instead
+            # are not gradients of this objective (gp_lml_grad returns them all the same: ``gower_gradients = 'fork'``
+            # follows the reference's optimiser); by default forward differences of the device LML are used instead
             f = self.objective_function()
             g = np.empty_like(x)
             for i in range(x.size):

@@ -187,16 +187,33 @@ def test_gower_front_door_as_run_py_calls_it():
     bo.model.model.close()
 
 
-def test_gower_hyper_gradients_stay_refused_and_optimise_by_differences():
-    """gp_lml_grad of a Gower model is the one sanctioned refusal: the host optimises on differences of the
-    device LML and must not lower it."""
-    c = Case(G, TAGS[0])
+@pytest.mark.parametrize("tag", [t for t in TAGS if "_N64_" in t or "_N300_" in t])
+def test_gower_hyper_gradients_are_the_forks(tag):
+    """gp_lml_grad of a Gower model == the fork's update_gradients_full (stationary.py:218-238 restated in the oracle): the
+    Gower K weighs the variance gradient, the Euclidean dK/dr on the kernel's own lengthscale makes the lengthscale gradient
+    -- although K does not depend on that lengthscale at all.  The host therefore optimises on differences of the device
+    LML by default (must not lower it); `gower_gradients = 'fork'` follows the reference's optimiser instead."""
+    c = Case(G, tag)
     space = gpo.Design_space(DOMAIN)
     m = _model(c, space)
+    kern0 = O.make_kernel("rbf" if int(c.kernel) == 0 else "Mat52", 6, float(c.variance), c.lengthscale, Gower=True,
+                          space=O.MixedSpace(DOMAIN))
+    dv0, dl0, dn0 = O.OracleGP(c.X, c.Y, kern0, float(c.noise)).gradients()
     m.log_likelihood()
-    with pytest.raises(RuntimeError, match="Gower"):
-        m._h.lml_grad(1)
+    dv, dl, dn = m._h.lml_grad(1)
+    scale = max(abs(dv0), float(np.max(np.abs(dl0))), abs(dn0), 1.0)
+    tol = TOL if float(c.noise) >= 1e-4 else 1e-4      # Ky^-1 enters with 1 / noise: cond * eps on both float64 paths
+    assert abs(dv - dv0) <= tol * scale and np.max(np.abs(dl - dl0)) <= tol * scale and abs(dn - dn0) <= tol * max(abs(dn0), 1.0)
+    # the lengthscale gradient is not a derivative of this model's LML: K ignores the parameter
     l0 = m.log_likelihood()
-    m.optimize(max_iters=10)
-    assert m.log_likelihood() >= l0 - 1e-6
+    m.kern.lengthscale[:] = float(c.lengthscale[0]) * 1.5
+    assert abs(m.log_likelihood() - l0) <= 1e-9 * abs(l0) and np.max(np.abs(dl0)) > 0
+    m.kern.lengthscale[:] = float(c.lengthscale[0])
+    if "_N64_" in tag:
+        l0 = m.log_likelihood()
+        m.optimize(max_iters=10)
+        assert m.log_likelihood() >= l0 - 1e-6
+        m.gower_gradients = 'fork'
+        m.optimize(max_iters=5)                        # runs: the reference's own (inconsistent) search direction
+        assert np.isfinite(m.log_likelihood())
     m.close()

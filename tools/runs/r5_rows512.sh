@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/r5rows512
 mkdir -p $out
 for n in 512 2048; do
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$out/prof$n -o rows -- python3 $GRAFT_REPO_ROOT/tools/rows_trace.py $n 100 > $GRAFT_REPO_ROOT/$out/prof$n.log 2>&1) || exit 1
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$out/prof$n -o rows -- python3 $GRAFT_REPO_ROOT/tools/gpbench.py rows_trace $n 100 > $GRAFT_REPO_ROOT/$out/prof$n.log 2>&1) || exit 1
 done
 python3 - <<'PY'
 import sqlite3, glob

@@ -368,12 +368,12 @@ class Handle(object):
 
     # -- a handful of locations per call (include/gphip.h, gp_*_rows): set_candidates + the batched call in ONE entry point
     def predict_rows(self, Xs, include_noise=True, grad=False):
-        """(mean [M, 1], var [M, 1]) and, with ``grad``, (dmdx [M, D, 1], dvdx [M, D]) as well."""
+        """(mean [M, P], var [M, 1]) and, with ``grad``, (dmdx [M, D, P], dvdx [M, D]) as well."""
         Xs = as_f64(Xs, 2)
         M = Xs.shape[0]
-        mean, var = np.empty((M, 1)), np.empty((M, 1))
+        mean, var = np.empty((M, self.P)), np.empty((M, 1))
         if grad:
-            dm, dv = np.empty((M, self.D, 1)), np.empty((M, self.D))
+            dm, dv = np.empty((M, self.D, self.P)), np.empty((M, self.D))
             rc = self.lib.gp_predict_rows(self.h, Xs.ctypes.data, M, 1 if include_noise else 0, mean.ctypes.data,
                                           var.ctypes.data, dm.ctypes.data, dv.ctypes.data)
         else:

@@ -111,6 +111,22 @@ def test_random_case(h, case):
                 assert np.max(np.abs(a - a0)) < 1e-6 * max(1.0, np.max(np.abs(a0)))
                 idx, val = h.acq_argbest(t, par, fmin, -1)
                 assert idx == int(np.argmin(a[:, 0])) and val == a[idx, 0]
+        # the one-call entry points for a handful of locations (fused over the inverse factor where they apply: P = 1 and the
+        # coordinates fit the kernel arguments; the batched calls inside otherwise) against the oracle, one and a few at a time
+        for k in sorted({1, min(M, 3), min(M, 5)}):
+            xs = Xs[:k]
+            if P == 1:
+                mr, vr, dmr, dvr = h.predict_rows(xs, True, grad=True)
+                assert relmax(mr, m0[:k]) < 1e-6 and np.max(np.abs(vr - v0[:k]) / np.abs(v0[:k])) < 1e-6
+                assert np.max(np.abs(dmr - dm0[:k])) < 1e-6 * max(1.0, np.max(np.abs(dm0)))
+                assert np.max(np.abs(dvr - dv0[:k])) < 1e-6 * max(1.0, np.max(np.abs(dv0)))
+                a0, da0 = O.acq_EI_withGradients(model, xs, 0.01, f0)
+                ar, dar = h.acq_rows(xs, _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+                assert np.max(np.abs(ar + a0)) < 1e-6 * max(1.0, np.max(np.abs(a0)))
+                assert np.max(np.abs(dar + da0)) < 1e-5 * max(1.0, np.max(np.abs(da0)))
+            else:
+                mr, vr = h.predict_rows(xs, True)
+                assert relmax(mr, m0[:k]) < 1e-6 and np.max(np.abs(vr - v0[:k]) / np.abs(v0[:k])) < 1e-6
     finally:
         h.set_option("panel_tiles", 6)
         h.set_option("mc_max", 16384)

@@ -234,3 +234,34 @@ def test_rows_calls_under_the_gower_kernel():
         _close(dv_r, dv_b, 1e-8)
     assert h.rows_stats()["fused"] >= 20
     gm.model.close()
+
+
+def test_rows_calls_beyond_the_infinity_cache_size():
+    """N = 8320 (65 tiles: the inverse factor's lower triangle passes 256 MiB, so its loads turn non-temporal) with one and
+    with three locations per call (the 4-vector kernels): against the batched calls, and option rows_nt = 0 / 1 give the
+    same bits (the load policy is not arithmetic)."""
+    h, X, Y, Xs, ls = _fitted(8320, 6, _lib.GP_KERNEL_MATERN52, False, 1e-2, seed=7)
+    fmin = h.fmin()
+    for M in (1, 3):
+        x = Xs[:M]
+        h.set_candidates(x)
+        mu_b, var_b = h.predict(True)
+        dm_b, dv_b = h.predict_grad()
+        a_b, da_b = h.acq_grad(_lib.GP_ACQ_EI, 0.01, fmin)
+        res = {}
+        for nt in (-1, 0, 1):
+            h.set_option("rows_nt", nt)
+            res[nt] = h.predict_rows(x, True, grad=True) + h.acq_rows(x, _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+        h.set_option("rows_nt", -1)
+        for a, b in zip(res[0], res[1]):
+            assert np.array_equal(a, b)
+        for a, b in zip(res[-1], res[1]):
+            assert np.array_equal(a, b)
+        mu, var, dm, dv, a, da = res[-1]
+        _close(mu, mu_b, 1e-9)
+        assert np.max(np.abs(var - var_b) / np.abs(var_b)) <= 1e-9
+        _close(dm, dm_b, 1e-9)
+        _close(dv, dv_b, 1e-8)
+        _close(a, a_b, 1e-8)
+        _close(da, da_b, 1e-7)
+    h.close()

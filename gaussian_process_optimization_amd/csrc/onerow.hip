@@ -6,7 +6,7 @@
 //     k* = K(X, x),  mean = k*^T alpha,  w = L^-1 k* (dtrtrs),  var = kss - |w|^2,  beta = Ky^-1 k*,
 //     d mean / dx = gradients_X(alpha^T, x, X),  d var / dx = gradients_X(-2 beta^T, x, X)       (stationary.py:336-364)
 // and the EI / LCB / MPI (+ local penalisation) chain rule on top.  With the inverse factor Li = L^-1 kept from the potri-
-// equivalent (api_rows.hip, ensure_linv; lower triangular, row-major) this is matrix-vector work bound by reading the lower
+// equivalent (api_solve.hip, ensure_linv; lower triangular, row-major) this is matrix-vector work bound by reading the lower
 // triangle of Li twice (2 x 8 N^2 / 2 bytes: 2.15 GB at N = 16384):
 //
 //   rows_forward_kernel    w = Li k*           row dots; k* generated on the fly per 1024-column chunk (never stored)

@@ -103,6 +103,7 @@ static void apply_fit_record(gp_ctx *g, const double *rec) {
     g->fmin_valid = false;
     g->wi_valid = false;
     g->li_valid = false;
+    g->rows_calls_since_fit = 0;
     g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;

@@ -399,6 +399,7 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
         g->lauum_panels = (int)value;
         g->wi_valid = false;
         g->li_valid = false;
+        g->rows_calls_since_fit = 0;
         g->w_in_t2 = false;
     } else if (!strcmp(name, "side_alpha")) {
         g->side_alpha = (int)value;
@@ -446,6 +447,9 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "debug_potrf_lds")) {
         if (value < 0 || value > (1 << 20)) return fail(GP_ERR_ARG, "debug_potrf_lds out of range");
         potrf_set_debug_lds((int)value);   // process-wide test hook: forces refused diagonal-tile launches (tests/test_gpu_round4.py)
+    } else if (!strcmp(name, "rows_build")) {
+        if (value < -1 || value > 1) return fail(GP_ERR_ARG, "rows_build out of range (-1: by rule, 0: never, 1: at the first call)");
+        g->rows_build = (int)value;
     } else if (!strcmp(name, "rows_nt")) {
         if (value < -1 || value > 1) return fail(GP_ERR_ARG, "rows_nt out of range (-1: automatic, 0, 1)");
         g->rows_nt = (int)value;
@@ -514,6 +518,7 @@ extern "C" int gp_set_data(gp_t *g, const double *X, const double *Y, int64_t N,
     g->fmin_valid = false;
     g->wi_valid = false;
     g->li_valid = false;
+    g->rows_calls_since_fit = 0;
     g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;
@@ -542,6 +547,7 @@ extern "C" int gp_set_gower(gp_t *g, int enable, const int *is_discrete, const d
     g->fmin_valid = false;
     g->wi_valid = false;
     g->li_valid = false;
+    g->rows_calls_since_fit = 0;
     g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;
@@ -565,6 +571,7 @@ extern "C" int gp_set_params(gp_t *g, int kernel, int ard, double variance, cons
     g->fmin_valid = false;
     g->wi_valid = false;
     g->li_valid = false;
+    g->rows_calls_since_fit = 0;
     g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;
@@ -665,6 +672,7 @@ extern "C" int gp_kernel_matrix(gp_t *g, double *K) {
     g->fitted = false;  // dA was overwritten
     g->wi_valid = false;
     g->li_valid = false;
+    g->rows_calls_since_fit = 0;
     g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;

@@ -396,6 +396,7 @@ int fit_impl(gp_ctx *g, int maxtries, int pipe, int include_noise) {
     g->fmin_valid = false;
     g->wi_valid = false;
     g->li_valid = false;
+    g->rows_calls_since_fit = 0;
     g->w_in_t2 = false;
     g->invp_valid = false;
     g->lr_valid = false;

@@ -122,6 +122,8 @@ struct gp_ctx {
     std::vector<double> lp_cache;        // local-penalisation batch as last uploaded (Xb | r | s), skipped when unchanged
     int lp_cache_nb = -1;
     long rows_fused_calls = 0, rows_fallback_calls = 0;
+    long rows_calls_since_fit = 0;       // *_rows calls that wanted the inverse factor since the last fit (build policy, api_rows.hip)
+    int rows_build = -1;                 // inverse factor of the one-location path: -1 by the rule of api_rows.hip, 0 never, 1 at the first call (option "rows_build")
     int rows_nt = -1;                    // fused one-row path: non-temporal loads of the inverse factor (option "rows_nt"; -1: when its
                                          // lower triangle exceeds the 256 MiB Infinity Cache, N > 8192 -- measured -10 % at N = 16384,
                                          // +10 % at N = 4096 where the next call finds the factor cached: profiles/r05_small_calls.txt)

@@ -9,6 +9,18 @@ static bool rows_fused_ok(const gp_ctx *g, int64_t M) {
     return g->small_m > 0 && M >= 1 && M <= g->small_m && g->P == 1 && (long)std::min<int64_t>(M, ROWS_MAX_M) * g->D <= ROWS_MAX_XS;
 }
 
+// When to build the inverse factor (N^3 / 3 flops once per fit: 0.7 ms at N = 4096, 28 ms at N = 16384).  A call through the
+// substitution route (~90 short launches against L, no precomputation) costs about 3x a fused call, so the factor pays for
+// itself after build / (substitution - fused) calls: ~8 at N = 8192, ~32 at N = 16384.  Not knowing how many calls will follow a
+// fit, the rule is the ski-rental one -- rent until the rent paid equals the price: the first nt / 4 calls after a fit take the
+// substitution route, the next one builds the factor (never worse than twice the best choice in hindsight).  Small matrices
+// (N <= 4096) build at the first call; a factor that exists is always used.
+static bool rows_use_factor(gp_ctx *g) {
+    if (g->li_valid || g->N <= 4096 || g->rows_build == 1) return true;
+    if (g->rows_build == 0) return false;
+    return ++g->rows_calls_since_fit > g->Npad / GP_TILE / 4;
+}
+
 static int rows_scratch(gp_ctx *g, RowsWork *w) {
     const long Npad = g->Npad;
     const int nt = (int)(Npad / GP_TILE);
@@ -108,8 +120,7 @@ extern "C" int gp_predict_rows(gp_t *g, const double *Xs, int64_t M, int include
     if ((dmdx == nullptr) != (dvdx == nullptr)) return fail(GP_ERR_ARG, "dmdx and dvdx go together");
     HIPCHK(hipSetDevice(g->device));
     const int want_grad = dmdx != nullptr;
-    // the inverse factor costs N^3 / 3 once per fit: a posterior-only call builds it only where that is small change
-    if (rows_fused_ok(g, M) && (want_grad || g->li_valid || g->N <= 4096)) {
+    if (rows_fused_ok(g, M) && rows_use_factor(g)) {
         RowsAcq aq{};
         return rows_fused(g, Xs, (int)M, include_noise, want_grad, aq, mean, var, nullptr, dmdx, dvdx, nullptr);
     }
@@ -140,7 +151,7 @@ extern "C" int gp_acq_rows(gp_t *g, const double *Xs, int64_t M, int type, doubl
     HIPCHK(hipSetDevice(g->device));
     const int want_grad = dout != nullptr;
     int rc;
-    if (rows_fused_ok(g, M) && (want_grad || g->li_valid || g->N <= 4096)) {
+    if (rows_fused_ok(g, M) && rows_use_factor(g)) {
         RowsAcq aq{};
         aq.on = 1;
         aq.type = type;

@@ -45,6 +45,7 @@ def test_rows_calls_equal_the_batched_calls(N, D, kernel, ard, noise):
     inside) against gp_set_candidates + gp_predict / gp_predict_grad / gp_acq_grad / gp_acq_lp_grad.  Sizes cover one row
     block (N = 100), exactly one chunk, two chunks with a cut last one (N = 1100: 9 row blocks), and 36 row blocks."""
     h, X, Y, Xs, ls = _fitted(N, D, kernel, ard, noise, seed=N)
+    h.set_option("rows_build", 1)          # compare the fused path at every size (the default rule rents the first calls above N = 4096)
     Xs = Xs.copy()
     Xs[1] = X[3]                    # ON a training point: r = 0, the variance's worst case
     Xs[6] = X[N - 1]
@@ -241,6 +242,7 @@ def test_rows_calls_beyond_the_infinity_cache_size():
     with three locations per call (the 4-vector kernels): against the batched calls, and option rows_nt = 0 / 1 give the
     same bits (the load policy is not arithmetic)."""
     h, X, Y, Xs, ls = _fitted(8320, 6, _lib.GP_KERNEL_MATERN52, False, 1e-2, seed=7)
+    h.set_option("rows_build", 1)         # the inverse factor at the first call (the default rule would rent 16 calls first)
     fmin = h.fmin()
     for M in (1, 3):
         x = Xs[:M]
@@ -264,4 +266,51 @@ def test_rows_calls_beyond_the_infinity_cache_size():
         _close(dv, dv_b, 1e-8)
         _close(a, a_b, 1e-8)
         _close(da, da_b, 1e-7)
+    h.close()
+
+
+def test_inverse_factor_is_built_by_the_ski_rental_rule():
+    """Above N = 4096 the first nt / 4 one-location calls after a fit go through substitutions against L (no N^3 work: a
+    handful of calls must not pay for the inverse factor), the next call builds it and every later one is fused; the values
+    do not notice the switch.  `rows_build` = 0 never builds, = 1 builds at the first call; a refit starts over.  The
+    substitution route of gp_acq_grad needs no Ky^-1 either (two substitutions give beta)."""
+    h, X, Y, Xs, ls = _fitted(4500, 4, _lib.GP_KERNEL_RBF, False, 1e-2, seed=11)     # 36 tiles: 9 rented calls
+    fmin = h.fmin()
+    x = Xs[:1]
+    h.profile(True)
+    ref = None
+    for call in range(1, 13):
+        before = h.rows_stats()
+        a, da = h.acq_rows(x, _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+        after = h.rows_stats()
+        rented = call <= 9
+        assert (after["fallback"] - before["fallback"], after["fused"] - before["fused"]) == ((1, 0) if rented else (0, 1)), call
+        names = [p["name"] for p in h.phases()]
+        assert not any(n.startswith("potri_lauum") for n in names)            # Ky^-1 is never built on this route
+        if ref is None:
+            ref = (a, da)
+        _close(a, ref[0], 1e-9)
+        _close(da, ref[1], 1e-8)
+    h.profile(False)
+    # a refit starts the count again; the two switches
+    h.fit()
+    b0 = h.rows_stats()
+    h.acq_rows(x, _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+    assert h.rows_stats()["fallback"] == b0["fallback"] + 1
+    h.set_option("rows_build", 1)
+    h.predict_rows(x, True)
+    assert h.rows_stats()["fused"] == b0["fused"] + 1
+    h.fit()
+    h.set_option("rows_build", 0)
+    for _ in range(12):
+        h.acq_rows(x, _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+    assert h.rows_stats()["fused"] == b0["fused"] + 1
+    h.set_option("rows_build", -1)
+    # against the oracle, through the substitution route (fresh fit, first call)
+    h.fit()
+    gp0 = O.OracleGP(X, Y, O.RBF(4, 1.1, ls), 1e-2)
+    a0, da0 = O.acq_EI_withGradients(O.OracleGPModel(gp0), x, 0.01, fmin)
+    a, da = h.acq_rows(x, _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+    assert abs(a.item() + a0.item()) <= 1e-5 * max(abs(a0.item()), 1e-12)
+    np.testing.assert_allclose(da, -da0, rtol=0, atol=1e-5 * max(np.max(np.abs(da0)), 1e-12))
     h.close()

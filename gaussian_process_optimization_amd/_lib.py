@@ -335,8 +335,11 @@ class Handle(object):
               "gp_predict_full_cov")
         return mean, cov
 
-    def predict_grad(self):
+    def predict_grad(self, mean_only=False):
         dm = np.empty((self.M, self.D, self.P))
+        if mean_only:      # the mean's gradients alone: no Ky^-1, no K* Ky^-1 (include/gphip.h)
+            check(self.lib, self.lib.gp_predict_grad(self.h, dptr(dm), None), "gp_predict_grad")
+            return dm
         dv = np.empty((self.M, self.D))
         check(self.lib, self.lib.gp_predict_grad(self.h, dptr(dm), dptr(dv)), "gp_predict_grad")
         return dm, dv

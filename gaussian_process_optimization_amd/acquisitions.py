@@ -452,8 +452,10 @@ def estimate_L(model, bounds, storehistory=True):
     gradients come from ONE batched device call."""
     from scipy.optimize import minimize
 
+    mean_jac = getattr(model, "mean_gradients", None)      # the HIP model: d mean / dx without the variance's share of the work
+
     def neg_slope(pts):
-        jac, _ = model.predictive_gradients(np.atleast_2d(pts))
+        jac = mean_jac(np.atleast_2d(pts)) if mean_jac is not None else model.predictive_gradients(np.atleast_2d(pts))[0]
         return -np.sqrt((jac * jac).sum(1))
 
     box = np.asarray(list(bounds), dtype=float)

@@ -145,10 +145,21 @@ int run_predict_grad(gp_ctx *g) {
 }
 
 extern "C" int gp_predict_grad(gp_t *g, double *dmdx, double *dvdx) {
-    if (!g || !dmdx || !dvdx) return fail(GP_ERR_ARG, "null argument");
+    if (!g || !dmdx) return fail(GP_ERR_ARG, "null argument");
     GP_DEAD_CHECK(g);
     HIPCHK(hipSetDevice(g->device));
     int rc;
+    if (!dvdx) {
+        // the mean's gradients alone (what estimate_L maximises, batch_local_penalization.py:55-58): gradients_X(alpha^T, X*, X) needs
+        // neither Ky^-1 nor K(X*, X) Ky^-1 -- one pass of O(M N D) instead of 2 N^3 / 3 + N^2 M flops
+        if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
+        if (g->M < 1) return fail(GP_ERR_STATE, "gp_set_candidates first");
+        if ((rc = ensure_grad_buffers(g, std::max<long>(g->capCov, 1), g->M))) return rc;
+        launch_predict_grad(g->s, g->dXs, g->M, g->dX, g->N, g->kp, g->dAlpha, g->Npad, g->P, nullptr, 0, g->dDm, g->dDv);
+        HIPCHK(hipMemcpyAsync(dmdx, g->dDm, sizeof(double) * g->M * g->D * g->P, hipMemcpyDeviceToHost, g->s));
+        GP_SYNC(g->s);
+        return 0;
+    }
     if ((rc = run_predict_grad(g))) return rc;
     HIPCHK(hipMemcpyAsync(dmdx, g->dDm, sizeof(double) * g->M * g->D * g->P, hipMemcpyDeviceToHost, g->s));
     HIPCHK(hipMemcpyAsync(dvdx, g->dDv, sizeof(double) * g->M * g->D, hipMemcpyDeviceToHost, g->s));

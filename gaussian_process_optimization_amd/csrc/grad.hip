@@ -230,7 +230,7 @@ void launch_lml_grad(hipStream_t s, const double *X, long N, long Npad, const Ke
 //   dvdx[m, q]    = sum_n g(r_mn) (-2 beta[m, n]) (xs_mq - x_nq) / l_q^2,   beta = K(Xs, X) Ky^-1
 __global__ __launch_bounds__(256) void predict_grad_kernel(const double *Xs, const double *X, long N, KernParams kp,
                                                            const double *alpha, long lda_, int P, const double *beta,
-                                                           long ldb, int d0, double *dmdx, double *dvdx) {
+                                                           long ldb, int d0, double *dmdx, double *dvdx, int first_pass) {
     __shared__ double xs[GP_MAX_D];
     __shared__ double red[4][GCH];
     const int D = kp.D;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void predict_grad_kernel(const double *Xs, con
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
     // pass A: variance gradient; passes p: mean gradients (weights differ, geometry identical)
-    for (int pass = 0; pass <= P; ++pass) {
+    for (int pass = first_pass; pass <= P; ++pass) {   // first_pass = 1: mean gradients only (beta not read)
         double acc[GCH];
 #pragma unroll
         for (int q = 0; q < GCH; ++q) acc[q] = 0.0;
@@ -286,9 +286,10 @@ __global__ __launch_bounds__(256) void predict_grad_kernel(const double *Xs, con
 void launch_predict_grad(hipStream_t s, const double *Xs, long M, const double *X, long N, const KernParams &kp,
                          const double *alpha, long lda_, int P, const double *beta, long ldb, double *dmdx,
                          double *dvdx) {
+    // beta == nullptr: the mean's gradients only (dvdx untouched)
     for (int d0 = 0; d0 < kp.D; d0 += GCH)
         GP_LAUNCH(predict_grad_kernel, dim3((unsigned)M), dim3(256), 0, s, Xs, X, N, kp, alpha, lda_, P, beta,
-                           ldb, d0, dmdx, dvdx);
+                           ldb, d0, dmdx, dvdx, beta ? 0 : 1);
 }
 
 // ---- acquisition gradients (EI.py:42-51, LCB.py:39-46, MPI.py:42-51; gpmodel.py:131-142) ------------

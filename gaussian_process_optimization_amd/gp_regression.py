@@ -354,6 +354,18 @@ class GPRegression(Parameterized):
         self._stage(Xnew)
         return self._h.predict_grad()
 
+    def mean_gradients(self, Xnew):
+        """d mean / dx [M, D, P] alone -- the first output of ``predictive_gradients`` (gp.py:433-438) without the work of
+        the second: what ``estimate_L`` maximises over 500 + N points (batch_local_penalization.py:55-64)."""
+        Xn = np.asarray(Xnew, dtype=float)
+        if Xn.ndim == 2 and Xn.shape[0] == 0:
+            return np.empty((0, self.input_dim, self.output_dim))
+        few = self._few_rows(Xnew)
+        if few is not None:
+            return self._h.predict_rows(few, grad=True)[2]
+        self._stage(Xnew)
+        return self._h.predict_grad(mean_only=True)
+
     def posterior_covariance_between_points(self, X1, X2):
         """gp.py:714-721 -> Posterior.covariance_between_points (posterior.py:109-128):
         K(X1, X2) - (L^-1 K(X, X1))^T (L^-1 K(X, X2)), in the model's (normalised) output space.  Served by the

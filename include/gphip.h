@@ -159,7 +159,9 @@ int gp_predict_full_cov(gp_t *gp, int include_noise, double *mean, double *cov);
 int gp_posterior_samples(gp_t *gp, int include_noise, const double *Z, int S, int maxtries, double *mean, double *dev,
                          double *jitter_used);
 
-/* GP.predictive_gradients (gp.py:407-454): dmdx[M,D,P], dvdx[M,D]. */
+/* GP.predictive_gradients (gp.py:407-454): dmdx[M,D,P], dvdx[M,D].  dvdx = NULL: the mean's gradients alone
+ * (gradients_X(alpha^T, X*, X), gp.py:433-438) -- what estimate_L maximises over 500 + N points
+ * (GPyOpt/GPyOpt/core/evaluators/batch_local_penalization.py:55-64); they need neither Ky^-1 nor K(X*, X) Ky^-1. */
 int gp_predict_grad(gp_t *gp, double *dmdx, double *dvdx);
 
 /* GPModel.get_fmin (GPyOpt/GPyOpt/models/gpmodel.py:125-129): min over the training

@@ -427,6 +427,24 @@ def test_gower_mixed_variable_kernel():
     gm.model.close()
 
 
+def test_mean_gradients_alone_equal_the_first_output_of_predictive_gradients():
+    """gp_predict_grad with dvdx = NULL (GPRegression.mean_gradients; what estimate_L asks for on 500 + N points) == the first
+    output of the full call, for a batch and for a handful of rows, and needs no Ky^-1."""
+    X, Y, Xs = O.synthetic_problem(700, 3, 300, seed=8)
+    m = gpo.models.GPRegression(X, Y, gpo.kern.Matern52(3, 1.2, [0.4, 0.5, 0.6], ARD=True), noise_var=0.02)
+    m._h.profile(True)
+    jm = m.mean_gradients(Xs)
+    assert "potri_lauum" not in [p["name"] for p in m._h.phases()]
+    m._h.profile(False)
+    dm, dv = m.predictive_gradients(Xs)
+    assert jm.shape == dm.shape == (300, 3, 1) and np.array_equal(jm, dm)
+    np.testing.assert_allclose(m.mean_gradients(Xs[:3]), dm[:3], rtol=0, atol=1e-10 * np.max(np.abs(dm)))
+    assert m.mean_gradients(np.empty((0, 3))).shape == (0, 3, 1)
+    gp0 = O.OracleGP(X, Y, O.make_kernel("Mat52", 3, 1.2, [0.4, 0.5, 0.6], ARD=True), 0.02)
+    np.testing.assert_allclose(jm, gp0.predictive_gradients(Xs)[0], rtol=0, atol=1e-6 * np.max(np.abs(dm)))
+    m.close()
+
+
 def test_empty_candidate_set_and_shape_errors():
     """Zero prediction rows give the empty arrays NumPy gives the reference; wrong column counts raise."""
     rng = np.random.RandomState(0)

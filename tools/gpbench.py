@@ -950,6 +950,36 @@ def opt_sweep():
     h.close()
 
 
+@command
+def lp_driver_timing():
+    """The thesis driver's call (run.py:1206-1258) end to end at fixed hyper-parameters: BayesianOptimization(Gower, local penalisation,
+    batch of 5).suggest_next_locations() and the candidate-table loop over 20 000 rows, N = 300 and 4000 (test tooling)."""
+    import time
+    import numpy as np
+    import gaussian_process_optimization_amd as gpo
+    for N in (300, 4000):
+        D = 6
+        rng = np.random.default_rng(3)
+        dom = [{'name': 'm', 'type': 'discrete', 'domain': tuple(range(6))}, {'name': 'p', 'type': 'discrete', 'domain': tuple(range(9))},
+               {'name': 'q', 'type': 'discrete', 'domain': tuple(range(4))}, {'name': 'r', 'type': 'discrete', 'domain': tuple(range(3))},
+               {'name': 'c', 'type': 'continuous', 'domain': (12.0, 48.0)}, {'name': 'l', 'type': 'continuous', 'domain': (25.4, 100.0)}]
+        sp = gpo.Design_space(dom)
+        X = sp.samples_uniform(N)
+        Y = (np.sin(X[:, 4] / 7) + 0.3 * np.cos(X[:, 0]) + 0.2 * (X[:, 2] == 1) + 0.01 * (X[:, 5] - 60) ** 2 / 100)[:, None] + 0.02 * rng.standard_normal((N, 1))
+        table = sp.samples_uniform(20000)
+        for gower in (True, False):
+            bo = gpo.methods.BayesianOptimization(f=None, domain=dom, X=X, Y=Y, acquisition_type='EI', normalize_Y=True, exact_feval=True,
+                                                  acquisition_optimizer_type='lbfgs', evaluator_type='local_penalization', batch_size=5,
+                                                  Gower=gower, noise_var=0, max_iters=0)
+            np.random.seed(1); bo.suggest_next_locations()
+            np.random.seed(1)
+            t0 = time.perf_counter(); bo.suggest_next_locations(); t1 = time.perf_counter() - t0
+            np.random.seed(1)
+            t0 = time.perf_counter(); rows = bo.evaluator.compute_batch_from_table(table, sense=+1); t2 = time.perf_counter() - t0
+            print("N=%d Gower=%s: suggest_next_locations (LP batch of 5, L-BFGS) %.1f ms; table loop over 20000 rows %.1f ms" % (N, gower, t1 * 1e3, t2 * 1e3), flush=True)
+            bo.model.model.close()
+
+
 def main():
     if len(sys.argv) < 2 or sys.argv[1] in ("-h", "--help", "--list"):
         print(__doc__)

@@ -342,6 +342,7 @@ class AcquisitionLP(AcquisitionBase):
         # LCB can be negative, so its plain logarithm is replaced by log(softplus) (LP.py:32-35)
         self.transform = 'softplus' if (kind == 'none' and isinstance(acquisition, AcquisitionLCB)) else kind
         self.X_batch = self.r_x0 = self.s_x0 = None
+        self._lp_packed = None
 
     def update_batches(self, X_batch, L, Min):
         """Set (or with None: clear) the batch chosen so far; radii and widths of its exclusion balls come from the model's
@@ -349,6 +350,7 @@ class AcquisitionLP(AcquisitionBase):
         self.X_batch, have_batch = X_batch, X_batch is not None
         if have_batch:
             self.r_x0, self.s_x0 = self._ball_parameters(X_batch, L, Min)
+        self._lp_packed = None          # (transform, Xb, r, s) as contiguous float64, built once per batch (see _lp_few)
 
     def _ball_parameters(self, centres, L, Min):
         mu, spread = self.model.predict(np.atleast_2d(centres))
@@ -395,7 +397,18 @@ class AcquisitionLP(AcquisitionBase):
         if few is None:
             return None
         x, gp, fmin, shift, scale = few
-        lp = (1 if self.transform == 'softplus' else 0, self.X_batch, self.r_x0, self.s_x0)
+        src = (self.X_batch, self.r_x0, self.s_x0, self.transform)
+        held = getattr(self, "_lp_packed", None)
+        lp = held[1] if held is not None and all(a is b for a, b in zip(held[0], src)) else None
+        if lp is None:      # an L-BFGS run makes hundreds of calls with one batch: convert it once (per object identity of the
+            tr = 1 if self.transform == 'softplus' else 0          # batch attributes: assigning new arrays renews it)
+            if self.X_batch is None:
+                lp = (tr, None, None, None)
+            else:
+                lp = (tr, np.ascontiguousarray(np.atleast_2d(self.X_batch), dtype=float),
+                      np.ascontiguousarray(np.atleast_1d(self.r_x0), dtype=float),
+                      np.ascontiguousarray(np.atleast_1d(self.s_x0), dtype=float))
+            self._lp_packed = (src, lp)
         return gp._h.acq_rows(x, self.acq._acq_id, self.acq._par(), fmin, shift, scale, grad=grad, lp=lp)
 
     def acquisition_function(self, x):

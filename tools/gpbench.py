@@ -964,6 +964,7 @@ def lp_driver_timing():
                {'name': 'q', 'type': 'discrete', 'domain': tuple(range(4))}, {'name': 'r', 'type': 'discrete', 'domain': tuple(range(3))},
                {'name': 'c', 'type': 'continuous', 'domain': (12.0, 48.0)}, {'name': 'l', 'type': 'continuous', 'domain': (25.4, 100.0)}]
         sp = gpo.Design_space(dom)
+        np.random.seed(N)                       # the design, the table and estimate_L draw from numpy's global generator
         X = sp.samples_uniform(N)
         Y = (np.sin(X[:, 4] / 7) + 0.3 * np.cos(X[:, 0]) + 0.2 * (X[:, 2] == 1) + 0.01 * (X[:, 5] - 60) ** 2 / 100)[:, None] + 0.02 * rng.standard_normal((N, 1))
         table = sp.samples_uniform(20000)

@@ -43,3 +43,69 @@ def test_gower_space_and_table_loop_verbatim():
 def test_reference_test_invariants():
     # pinv closed form, var >= 0, normaliser equivalence, finite-difference gradients (no reference import needed)
     pin.check_invariants()
+
+
+@needs_ref
+def test_product_design_space_against_the_verbatim_one():
+    """The host mirror's Design_space (bounds, Gower additions, rounding of an optimiser's end point onto the domain) against
+    the reference's own class (GPyOpt/GPyOpt/core/task/space.py:263-272,328-362,436-445,483-492), imported verbatim."""
+    import importlib
+    import numpy as np
+    import gaussian_process_optimization_amd as gpo
+    ref_leaf.load_acquisitions()
+    space_mod = importlib.import_module("GPyOpt.core.task.space")
+    dom = [{'name': 'm', 'type': 'discrete', 'domain': tuple(range(6))}, {'name': 'p', 'type': 'discrete', 'domain': (1, 4, 9, 16)},
+           {'name': 'c', 'type': 'continuous', 'domain': (12.0, 48.0)}, {'name': 'q', 'type': 'discrete', 'domain': (0, 1)},
+           {'name': 'l', 'type': 'continuous', 'domain': (-2.5, 100.0)}]
+    ref, mine = space_mod.Design_space(dom), gpo.Design_space(dom)
+    assert ref.get_bounds() == mine.get_bounds()
+    assert ref.lengthscales() == mine.lengthscales()
+    assert ref.get_continuous_dims() == mine.get_continuous_dims() and ref.get_discrete_dims() == mine.get_discrete_dims()
+    assert ref.dimensionality == mine.dimensionality and ref.model_dimensionality == mine.model_dimensionality
+    assert ref.has_constraints() == mine.has_constraints()
+    rng = np.random.default_rng(0)
+    lo = np.array([b[0] for b in ref.get_bounds()], dtype=float)
+    hi = np.array([b[1] for b in ref.get_bounds()], dtype=float)
+    for _ in range(200):
+        x = lo + (hi - lo) * rng.uniform(-0.1, 1.1, 5)          # also a little outside the box, as a line search may end
+        np.testing.assert_array_equal(np.asarray(ref.round_optimum(x), dtype=float), mine.round_optimum(x))
+    x = rng.uniform(0, 1, (7, 5))
+    np.testing.assert_array_equal(ref.indicator_constraints(x), mine.indicator_constraints(x))
+
+
+@needs_ref
+def test_product_host_helpers_against_the_verbatim_ones():
+    """The host mirror's remaining arithmetic helpers against the reference's own (GPyOpt/GPyOpt/util/general.py): `normalize`
+    (:203-234, both modes), `get_quantiles` (:113-129) and the sampling stream `estimate_L` draws its 500 starting points from
+    (`samples_multidimensional_uniform`, :63-73) -- bit for bit."""
+    import numpy as np
+    import gaussian_process_optimization_amd as gpo
+    from gaussian_process_optimization_amd import acquisitions as A
+    from gaussian_process_optimization_amd.bayesian_optimization import normalize
+    _, _, _, general = ref_leaf.load()
+    rng = np.random.default_rng(1)
+    Y = rng.standard_normal((37, 1)) * 3.0 + 5.0
+    for mode in ("stats", "maxmin"):
+        assert np.array_equal(normalize(Y, mode), general.normalize(Y, mode))
+    m, s = rng.standard_normal((50, 1)), np.abs(rng.standard_normal((50, 1))) * 0.3
+    s[3] = 1e-12                                            # below the floor
+    got = A.get_quantiles(0.01, -0.2, m, s.copy())
+    ref = general.get_quantiles(0.01, -0.2, m, s.copy())
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    bounds = [(0, 5), (12.0, 48.0), (-1.0, 1.0)]
+    np.random.seed(5)
+    ref_draws = general.samples_multidimensional_uniform(bounds, 500)
+
+    class _Flat(object):                                    # estimate_L's model: only the draws matter here
+        X = np.zeros((1, 3))
+        seen = None
+
+        def predictive_gradients(self, x):
+            if self.seen is None:
+                self.seen = np.array(x[:500])
+            return np.zeros((x.shape[0], 3, 1)), np.zeros((x.shape[0], 3))
+    flat = _Flat()
+    np.random.seed(5)
+    assert gpo.estimate_L(flat, bounds) == 10                # a flat model: the reference's fallback value
+    assert np.array_equal(flat.seen, ref_draws)

@@ -127,12 +127,15 @@ class Design_space(object):
         return samples[0:n, :]
 
     def _samples_box(self, n, rng=np.random):
-        """experiment_design/random_design.py:37-65."""
+        """experiment_design/random_design.py:37-65: every discrete variable first (one ``choice`` call each, in order), then
+        every continuous one (one ``uniform`` call each, in order) -- the reference's consumption of the generator, so that a
+        seeded run draws the reference's design whatever the order of the variables."""
         Z = np.empty((n, self.dimensionality))
         for i, (t, d) in enumerate(zip(self.types, self.domains)):
             if t == 'discrete':
                 Z[:, i] = rng.choice(np.asarray(d, dtype=float), n)
-            else:
+        for i, (t, d) in enumerate(zip(self.types, self.domains)):
+            if t != 'discrete':
                 Z[:, i] = rng.uniform(d[0], d[1], n)
         return Z
 

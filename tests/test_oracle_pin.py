@@ -109,3 +109,108 @@ def test_product_host_helpers_against_the_verbatim_ones():
     np.random.seed(5)
     assert gpo.estimate_L(flat, bounds) == 10                # a flat model: the reference's fallback value
     assert np.array_equal(flat.seen, ref_draws)
+
+
+@needs_ref
+def test_product_design_samples_and_acquisition_optimiser_against_the_verbatim_ones():
+    """Under the same numpy seed the host mirror draws the reference's random design (experiment_design/random_design.py, with and
+    without constraints, discrete and continuous variables in any order) and its acquisition optimiser ends where the reference's
+    pieces end: anchors = the 5 best of 1000 random points, then the verbatim `apply_optimizer(OptLbfgs(bounds), anchor, ...)`
+    (optimization/optimizer.py:28-61,130-168) from each and the minimum -- on an oracle-backed EI.  (anchor_points_generator.py
+    itself needs the experiment_design package, whose __init__ imports the absent pyDOE: its five lines are replayed.)"""
+    import importlib
+    import numpy as np
+    import gaussian_process_optimization_amd as gpo
+    from gaussian_process_optimization_amd.bayesian_optimization import AcquisitionOptimizer
+    from oracle import cpu_ref as O
+    ref_leaf.load_acquisitions()
+    ref_leaf._pkg("GPyOpt.optimization", ref_leaf.REF + "/GPyOpt/GPyOpt/optimization")
+    ref_leaf._pkg("GPyOpt.experiment_design", ref_leaf.REF + "/GPyOpt/GPyOpt/experiment_design")
+    space_mod = importlib.import_module("GPyOpt.core.task.space")
+    rd = importlib.import_module("GPyOpt.experiment_design.random_design")
+    opt = importlib.import_module("GPyOpt.optimization.optimizer")
+    dom = [{'name': 'c', 'type': 'continuous', 'domain': (0.0, 1.0)}, {'name': 'm', 'type': 'discrete', 'domain': (0, 1, 2)},
+           {'name': 'l', 'type': 'continuous', 'domain': (-1.0, 2.0)}, {'name': 'q', 'type': 'discrete', 'domain': (0.0, 0.5, 1.0)}]
+    for cons in (None, [{'name': 'k', 'constraint': 'x[:,0] + x[:,2] - 1.5'}]):
+        ref, mine = space_mod.Design_space(dom, cons), gpo.Design_space(dom, cons)
+        np.random.seed(12)
+        a = rd.RandomDesign(ref).get_samples(300)
+        np.random.seed(12)
+        b = mine.samples_uniform(300)
+        assert np.array_equal(a, b)
+    # the acquisition optimiser on a continuous box with an oracle EI
+    X, Y, _ = O.synthetic_problem(60, 2, 4, seed=4)
+    gm = O.OracleGPModel(O.OracleGP(X, Y, O.make_kernel("Mat52", 2, 1.0, [0.3]), 1e-3))
+    fmin = gm.get_fmin()
+    f = lambda x: -O.acq_EI(gm, np.atleast_2d(x), 0.01, fmin)                                       # noqa: E731
+    f_df = lambda x: tuple(-v for v in O.acq_EI_withGradients(gm, np.atleast_2d(x), 0.01, fmin))      # noqa: E731
+    box = [{'name': 'x', 'type': 'continuous', 'domain': (0.0, 1.0), 'dimensionality': 2}]
+    ref, mine = space_mod.Design_space(box), gpo.Design_space(box)
+    np.random.seed(3)
+    Xd = rd.RandomDesign(ref).get_samples(1000)
+    anchors = Xd[np.argsort(f(Xd).flatten())[:5], :]                                                  # anchor_points_generator.py:59-61
+    lb = opt.OptLbfgs(ref.get_bounds())
+    ends = [opt.apply_optimizer(lb, a, f=f, df=None, f_df=f_df, space=ref) for a in anchors]
+    x_ref, fx_ref = min(ends, key=lambda t: t[1])                                                     # acquisition_optimizer.py:74-77
+    np.random.seed(3)
+    x_mine, fx_mine = AcquisitionOptimizer(mine, 'lbfgs').optimize(f=f, f_df=f_df)
+    assert np.array_equal(np.asarray(x_ref), x_mine) and float(np.ravel(fx_ref)[0]) == fx_mine
+
+
+@needs_ref
+def test_product_host_acquisition_layer_against_the_verbatim_one():
+    """The host mirror's acquisition classes on a FOREIGN model (an oracle-backed BOModel: the `_Rule` formulas and the host side
+    of AcquisitionLP / LocalPenalization / estimate_L, what the device path falls back to for models it cannot see) against the
+    reference's verbatim EI / LCB / MPI / LP classes and its LocalPenalization.compute_batch on the same model."""
+    import numpy as np
+    import gaussian_process_optimization_amd as gpo
+    from oracle import cpu_ref as O
+    A = ref_leaf.load_acquisitions()
+    X, Y, Xs = O.synthetic_problem(70, 2, 50, seed=6)
+    gm = O.OracleGPModel(O.OracleGP(X, Y, O.make_kernel("rbf", 2, 1.2, [0.35]), 1e-2))
+    gm.analytical_gradient_prediction = True
+    space = pin._Space([(0.0, 1.0)] * 2)
+    pairs = [(gpo.AcquisitionEI(gm, space, None, None, jitter=0.01), A["EI"].AcquisitionEI(gm, space, None, None, jitter=0.01)),
+             (gpo.AcquisitionLCB(gm, space, None, None, exploration_weight=2), A["LCB"].AcquisitionLCB(gm, space, None, None, exploration_weight=2)),
+             (gpo.AcquisitionMPI(gm, space, None, None, jitter=0.01), A["MPI"].AcquisitionMPI(gm, space, None, None, jitter=0.01))]
+    Xb = Xs[:3]
+    for mine, ref in pairs:
+        assert np.array_equal(mine.acquisition_function(Xs), ref.acquisition_function(Xs))
+        fm, dm = mine.acquisition_function_withGradients(Xs)
+        fr, dr = ref.acquisition_function_withGradients(Xs)
+        assert np.array_equal(fm, fr)
+        np.testing.assert_allclose(dm, dr, rtol=1e-12, atol=0)     # (the shared chain rule adds the two terms in another order)
+        lp_m = gpo.AcquisitionLP(gm, space, None, mine)
+        lp_r = A["LP"].AcquisitionLP(gm, space, None, ref)
+        assert lp_m.transform == lp_r.transform
+        for batch in (None, Xb):
+            lp_m.update_batches(batch, 2.5, float(Y.min()))
+            lp_r.update_batches(batch, 2.5, float(Y.min()))
+            if batch is not None:
+                assert np.array_equal(lp_m.r_x0, lp_r.r_x0) and np.array_equal(lp_m.s_x0, lp_r.s_x0)
+            np.testing.assert_allclose(lp_m.acquisition_function(Xs[4:]), lp_r.acquisition_function(Xs[4:]), rtol=1e-13, atol=0)
+            for r in range(4, 20, 5):      # the reference's gradient only broadcasts for one row at a time (LP.py:112-133)
+                gmine = lp_m.acquisition_function_withGradients(Xs[r:r + 1])[1]
+                gref = lp_r.d_acquisition_function(Xs[r:r + 1])
+                np.testing.assert_allclose(gmine, gref, rtol=1e-12, atol=1e-300)
+    # the batch loop with the acquisition's optimiser replaced by an arg-min over a table, as oracle/pin_against_reference.py does
+    table = Xs
+
+    def tabled(cls):
+        class T(cls):
+            def optimize(self, duplicate_manager=None):
+                a = self.acquisition_function(table)
+                i = int(np.argmin(a))
+                return table[i:i + 1], a[i]
+        return T
+    ev = A["lp_evaluator"]
+    saved = ev.estimate_L
+    ev.estimate_L = O.estimate_L          # (the reference's own indexes res.fun[0][0] and does not run on this scipy)
+    try:
+        np.random.seed(2)
+        B_ref = ev.LocalPenalization(tabled(A["LP"].AcquisitionLP)(gm, space, None, pairs[0][1]), 4).compute_batch()
+    finally:
+        ev.estimate_L = saved
+    np.random.seed(2)
+    B_mine = gpo.LocalPenalization(tabled(gpo.AcquisitionLP)(gm, space, None, pairs[0][0]), 4).compute_batch()
+    assert np.array_equal(B_ref, B_mine)

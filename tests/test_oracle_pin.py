@@ -93,6 +93,16 @@ def test_product_host_helpers_against_the_verbatim_ones():
     ref = general.get_quantiles(0.01, -0.2, m, s.copy())
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
+    from gaussian_process_optimization_amd.gp_regression import Standardize
+    _, _, normalizer, _ = ref_leaf.load()
+    Ym = rng.standard_normal((40, 3)) * [1.0, 5.0, 0.2] + [0.0, -3.0, 10.0]
+    mine_n, ref_n = Standardize(), normalizer.Standardize()
+    mine_n.scale_by(Ym)
+    ref_n.scale_by(Ym)
+    assert np.array_equal(mine_n.mean, ref_n.mean) and np.array_equal(mine_n.std, ref_n.std)
+    assert np.array_equal(mine_n.normalize(Ym), ref_n.normalize(Ym))
+    assert np.array_equal(mine_n.inverse_mean(Ym[:5]), ref_n.inverse_mean(Ym[:5]))
+    assert np.array_equal(mine_n.inverse_variance(np.abs(Ym[:5, :1])), ref_n.inverse_variance(np.abs(Ym[:5, :1])))
     bounds = [(0, 5), (12.0, 48.0), (-1.0, 1.0)]
     np.random.seed(5)
     ref_draws = general.samples_multidimensional_uniform(bounds, 500)

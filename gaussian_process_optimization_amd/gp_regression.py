@@ -448,6 +448,42 @@ class GPRegression(Parameterized):
         self._ensure_fit()
         return res
 
+    def checkgrad(self, verbose=False, step=1e-6, tolerance=1e-3):
+        """paramz ``Model.checkgrad`` as the reference's tests call it (GPy/GPy/testing/model_tests.py:684-723,
+        kernel_tests.py:414-422: ``assert m.checkgrad()``), restated from its published behaviour: in the optimiser's
+        (transformed) space, the objective's central difference along ONE random sign vector of length ``step`` against the
+        analytic gradient's projection on it; True when their ratio is within ``tolerance`` of 1 (or both vanish).
+        ``verbose`` prints the per-parameter table instead and returns whether every parameter passes."""
+        x = self.optimizer_array.copy()
+        if x.size == 0:
+            return True
+        try:
+            if not verbose:
+                dx = step * np.sign(np.random.uniform(-1, 1, x.size))
+                f1 = self._obj_grad(x + dx)[0]
+                f2 = self._obj_grad(x - dx)[0]
+                grad = self._obj_grad(x)[1]
+                denominator = 2.0 * np.dot(dx, grad)
+                ratio = (f1 - f2) / (denominator if denominator != 0.0 else 1e-32)
+                both_flat = abs(f1 - f2) < tolerance and np.allclose(grad, 0, atol=tolerance)
+                return bool(abs(1.0 - ratio) < tolerance or both_flat)
+            grad = self._obj_grad(x)[1]
+            names = self.parameter_names_flat()
+            ok = True
+            print("%-32s | %12s | %12s | %12s" % ("Name", "Ratio", "Analytical", "Numerical"))
+            for i in range(x.size):
+                e = np.zeros_like(x)
+                e[i] = step
+                num = (self._obj_grad(x + e)[0] - self._obj_grad(x - e)[0]) / (2.0 * step)
+                ratio = num / grad[i] if grad[i] != 0.0 else np.inf
+                good = abs(1.0 - ratio) < tolerance or abs(num - grad[i]) < tolerance
+                ok = ok and good
+                print("%-32s | %12.6f | %12.6f | %12.6f%s" % (names[i] if i < len(names) else i, ratio, grad[i], num,
+                                                           "" if good else "   <-- FAIL"))
+            return bool(ok)
+        finally:
+            self.optimizer_array = x
+
     def randomize(self):
         """paramz Parameterized.randomize: N(0,1) draws in the optimiser space."""
         x = np.random.normal(size=self.optimizer_array.size)

@@ -427,6 +427,31 @@ def test_gower_mixed_variable_kernel():
     gm.model.close()
 
 
+@pytest.mark.parametrize("kname,ard", [("RBF", False), ("RBF", True), ("Matern52", False), ("Matern52", True)])
+def test_checkgrad_as_the_reference_tests_use_it(kname, ard):
+    """The reference pins its gradients by `assert m.checkgrad()` (GPy/GPy/testing/model_tests.py:684-723 on GPRegression with
+    RBF / Matern-5/2, iso and ARD; kernel_tests.py:414-422): the same call on the HIP model, at the initial and at randomised
+    hyper-parameters, silent and verbose; with a fixed noise (GPyOpt's exact_feval) too; and a wrong gradient fails it."""
+    np.random.seed(7)
+    X = np.random.uniform(-3., 3., (60, 3))
+    Y = np.sin(X[:, :1]) + 0.5 * np.cos(2 * X[:, 1:2]) + 0.05 * np.random.randn(60, 1)
+    k = getattr(gpo.kern, kname)(3, ARD=ard)
+    m = gpo.models.GPRegression(X, Y, k)
+    assert m.checkgrad()
+    m.randomize()
+    assert m.checkgrad() and m.checkgrad(verbose=True)
+    m.Gaussian_noise.constrain_fixed(1e-3, warning=False)
+    assert m.checkgrad()
+    x0 = m.optimizer_array.copy()
+    m.checkgrad()
+    assert np.allclose(m.optimizer_array, x0, rtol=1e-13, atol=0)    # the model is left where it was (up to the transform round trip)
+    real = m._obj_grad
+    m._obj_grad = lambda x: (real(x)[0], 1.5 * real(x)[1])   # a gradient off by a factor
+    assert not m.checkgrad()
+    m._obj_grad = real
+    m.close()
+
+
 def test_mean_gradients_alone_equal_the_first_output_of_predictive_gradients():
     """gp_predict_grad with dvdx = NULL (GPRegression.mean_gradients; what estimate_L asks for on 500 + N points) == the first
     output of the full call, for a batch and for a handful of rows, and needs no Ky^-1."""

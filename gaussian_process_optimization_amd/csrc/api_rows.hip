@@ -9,16 +9,17 @@ static bool rows_fused_ok(const gp_ctx *g, int64_t M) {
     return g->small_m > 0 && M >= 1 && M <= g->small_m && g->P == 1 && (long)std::min<int64_t>(M, ROWS_MAX_M) * g->D <= ROWS_MAX_XS;
 }
 
-// When to build the inverse factor (N^3 / 3 flops once per fit: 0.7 ms at N = 4096, 28 ms at N = 16384).  A call through the
-// substitution route (~90 short launches against L, no precomputation) costs about 3x a fused call, so the factor pays for
-// itself after build / (substitution - fused) calls: ~8 at N = 8192, ~32 at N = 16384.  Not knowing how many calls will follow a
-// fit, the rule is the ski-rental one -- rent until the rent paid equals the price: the first nt / 4 calls after a fit take the
-// substitution route, the next one builds the factor (never worse than twice the best choice in hindsight).  Small matrices
-// (N <= 4096) build at the first call; a factor that exists is always used.
+// When to build the inverse factor (N^3 / 3 flops once per fit: 0.7 ms at N = 4096, 4.4 ms at N = 8192, 28 ms at N = 16384).  A gradient
+// call through the substitution route (~90 short launches against L, no precomputation) costs 1.84 ms at N = 16384 against 0.44 fused
+// (0.55 against 0.16 at N = 8192), so the factor pays for itself after build / (substitution - fused) = ~20 calls at N = 16384, ~11 at
+// N = 8192: about nt / 6 at either size.  Not knowing how many calls will follow a fit, the rule is the ski-rental one -- rent until
+// the rent paid equals the price: the first nt / 6 calls after a fit take the substitution route, the next one builds the factor
+// (never worse than twice the best choice in hindsight).  Small matrices (N <= 4096) build at the first call; a factor that exists is
+// always used.
 static bool rows_use_factor(gp_ctx *g) {
     if (g->li_valid || g->N <= 4096 || g->rows_build == 1) return true;
     if (g->rows_build == 0) return false;
-    return ++g->rows_calls_since_fit > g->Npad / GP_TILE / 4;
+    return ++g->rows_calls_since_fit > g->Npad / GP_TILE / 6;
 }
 
 static int rows_scratch(gp_ctx *g, RowsWork *w) {

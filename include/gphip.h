@@ -223,7 +223,7 @@ int gp_acq_lp_argbest(gp_t *gp, int type, double par, double fmin, double y_mean
  * named below, as ONE call taking the locations Xs[M, D] by value; for M <= option "small_m" (8) locations of a
  * single-output model with min(M, 4) D <= 128 they run as three launches (two for a value-only call) per pass of up to
  * four locations over the explicit inverse factor L^-1 (dtrtri, linalg.py:217-227; built once per fit -- at the first
- * call for N <= 4096, above that after the first N / 512 calls, which go through substitutions against L: option
+ * call for N <= 4096, above that after the first N / 768 calls, which go through substitutions against L: option
  * "rows_build" -- at half the work of Ky^-1) with no copy commands (csrc/onerow.hip), otherwise through the batched calls
  * themselves.  Same results either way to rounding
  * (tests/test_gpu_rows.py: 1e-9 on well-conditioned models, the north-star 1e-6 against the oracle everywhere); the

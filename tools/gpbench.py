@@ -584,6 +584,7 @@ def rows_trace():
     X = rng.uniform(0, 1, (N, D)); Y = rng.standard_normal((N, 1))
     h = _lib.Handle(0)
     h.set_option("emulate_fp64", 0)
+    h.set_option("rows_build", 1)      # steady state: the inverse factor at the first call (by default above N = 4096 only after N / 768 calls)
     for kv in sys.argv[3:]:
         k, v = kv.split("=")
         h.set_option(k, int(v))

@@ -386,6 +386,16 @@ class Handle(object):
             check(self.lib, rc, "gp_predict_rows")
         return (mean, var, dm, dv) if grad else (mean, var)
 
+    def mean_grad_rows(self, Xs):
+        """d mean / dx [M, D, P] of a handful of locations, alone: one pass over the training points (include/gphip.h)."""
+        Xs = as_f64(Xs, 2)
+        M = Xs.shape[0]
+        dm = np.empty((M, self.D, self.P))
+        rc = self.lib.gp_predict_rows(self.h, Xs.ctypes.data, M, 0, None, None, dm.ctypes.data, None)
+        if rc:
+            check(self.lib, rc, "gp_predict_rows")
+        return dm
+
     def acq_rows(self, Xs, type_, par, fmin, y_mean=0.0, y_std=1.0, grad=False, lp=None):
         """Negated acquisition [M, 1] (and its gradient [M, D]); ``lp`` = (transform, Xb, r_x0, s_x0) adds the local
         penalisation, in which case the value comes back 1-D as AcquisitionLP returns it."""

@@ -118,8 +118,33 @@ extern "C" int gp_predict_rows(gp_t *g, const double *Xs, int64_t M, int include
     GP_DEAD_CHECK(g);
     if (!g->fitted) return fail(GP_ERR_STATE, "gp_fit first");
     if (M < 1) return fail(GP_ERR_ARG, "M < 1");
-    if ((dmdx == nullptr) != (dvdx == nullptr)) return fail(GP_ERR_ARG, "dmdx and dvdx go together");
+    if (dvdx && !dmdx) return fail(GP_ERR_ARG, "dvdx needs dmdx");
+    if (dmdx && !dvdx && (mean || var)) return fail(GP_ERR_ARG, "the mean's gradient alone (dvdx NULL) comes without mean / var");
     HIPCHK(hipSetDevice(g->device));
+    if (dmdx && !dvdx) {
+        // d mean / dx alone: one pass over the training points, no inverse factor, no substitutions (estimate_L's inner call)
+        if (rows_fused_ok(g, M)) {
+            int rc;
+            RowsWork w;
+            if ((rc = rows_scratch(g, &w))) return rc;
+            for (int m0 = 0; m0 < (int)M; m0 += ROWS_MAX_M) {
+                const int mc = std::min(ROWS_MAX_M, (int)M - m0);
+                const int MV = mc == 1 ? 1 : ROWS_MAX_M;
+                RowsX rx;
+                rx.M = mc;
+                memcpy(rx.xs, Xs + (long)m0 * g->D, sizeof(double) * mc * g->D);
+                launch_rows_mean_grad(g->s, rx, g->kp, g->dX, g->N, g->dAlpha, w, g->hRowsOut);
+                GP_SYNC(g->s);
+                memcpy(dmdx + (long)m0 * g->D, g->hRowsOut + 3 * MV, sizeof(double) * mc * g->D);
+            }
+            ++g->rows_fused_calls;
+            return 0;
+        }
+        ++g->rows_fallback_calls;
+        int rc;
+        if ((rc = gp_set_candidates(g, Xs, M))) return rc;
+        return gp_predict_grad(g, dmdx, nullptr);
+    }
     const int want_grad = dmdx != nullptr;
     if (rows_fused_ok(g, M) && rows_use_factor(g)) {
         RowsAcq aq{};

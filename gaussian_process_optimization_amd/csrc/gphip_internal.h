@@ -213,6 +213,9 @@ size_t rows_gpart_elems(long N);
 void launch_rows(hipStream_t s, const double *Li, long Npad, const RowsX &rx, const KernParams &kp, const double *X, long N,
                  const double *alpha, int want_grad, double kss, double noise_add, const RowsAcq &aq, const RowsWork &w,
                  double *out, int nt_loads);
+// the mean's gradient alone: dmdx [M, D] at out + 3 MV (one pass over the training points, no inverse factor)
+void launch_rows_mean_grad(hipStream_t s, const RowsX &rx, const KernParams &kp, const double *X, long N, const double *alpha,
+                           const RowsWork &w, double *out);
 void launch_transpose_tri(hipStream_t s, double *dst, const double *src, long n, int mode);
 
 // ---- grad.hip ---------------------------------------------------------------------------------

@@ -376,6 +376,72 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(RowsX rx, KernParams k
     if (tid == 0) *counter = 0u;   // ready for the next call (stream-ordered behind this kernel)
 }
 
+// ---- the mean's gradient alone ---------------------------------------------------------------------------------------------------------
+// d mean / dx = gradients_X(alpha^T, x, X) (gp.py:433-438 over stationary.py:336-364) needs neither L^-1 nor k* products: one pass
+// over the training points.  What estimate_L's L-BFGS-B asks for, one location at a time and D + 1 times per step (it differentiates by
+// forward differences, batch_local_penalization.py:55-67).  grid = ceil(N / 256); the last workgroup to arrive adds the workgroups'
+// sums in workgroup order and writes dmdx [M, D] at out + 3 MV (the place rows_finish_kernel writes it).
+template <int MV>
+__global__ __launch_bounds__(256) void rows_mean_grad_kernel(RowsX rx, KernParams kp, const double *X, long N, const double *alpha,
+                                                             double *gpart, unsigned int *counter, double *out) {
+    __shared__ double xs_s[ROWS_MAX_XS];
+    __shared__ double sh[4][ROWS_MAX_XS];
+    __shared__ double fin_s[8][ROWS_MAX_XS];
+    __shared__ int last_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = kp.D, M = rx.M, nval = M * D;
+    for (int i = tid; i < nval; i += 256) xs_s[i] = rx.xs[i] / kp.ls[i % D];
+    __syncthreads();
+    const long n = (long)blockIdx.x * 256 + tid;
+    const bool live = n < N;
+    const double a = live ? alpha[n] : 0.0;
+    for (int m = 0; m < M; ++m) {
+        double s = 0.0;
+        if (live)
+            for (int d = 0; d < D; ++d) {
+                const double df = xs_s[m * D + d] - X[n * D + d] / kp.ls[d];
+                s = fma(df, df, s);
+            }
+        double kv, gv;
+        gp_k_and_g(kp.kernel, kp.variance, s, kv, gv);
+        if (s == 0.0) gv = 0.0;   // invdist = 0 where the distance is exactly 0 (stationary.py:251-258)
+        const double tm = live ? gv * a : 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double dq = live ? xs_s[m * D + d] - X[n * D + d] / kp.ls[d] : 0.0;
+            const double v = rw_wave_sum(tm * dq);
+            if (lane == 0) sh[wave][m * D + d] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < nval) gpart[(long)blockIdx.x * RW_GROW + tid] = ((sh[0][tid] + sh[1][tid]) + sh[2][tid]) + sh[3][tid];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last_s = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    for (int idx = tid; idx < 8 * nval; idx += 256) {
+        const int v = idx % nval, j = idx / nval;
+        fin_s[j][v] = rw_strided_sum(gpart + v, RW_GROW, j, 8, (int)gridDim.x);
+    }
+    __syncthreads();
+    for (int v = tid; v < nval; v += 256) {
+        double s = 0.0;
+        for (int j = 0; j < 8; ++j) s += fin_s[j][v];
+        out[3 * MV + (v / D) * D + v % D] = s / kp.ls[v % D];   // (x - x') / l^2 = scaled difference / l
+    }
+    if (tid == 0) *counter = 0u;
+}
+
+void launch_rows_mean_grad(hipStream_t s, const RowsX &rx, const KernParams &kp, const double *X, long N, const double *alpha,
+                           const RowsWork &w, double *out) {
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    if (rx.M == 1)
+        GP_LAUNCH(rows_mean_grad_kernel<1>, dim3(grid), dim3(256), 0, s, rx, kp, X, N, alpha, w.gpart, w.counter, out);
+    else
+        GP_LAUNCH(rows_mean_grad_kernel<ROWS_MAX_M>, dim3(grid), dim3(256), 0, s, rx, kp, X, N, alpha, w.gpart, w.counter, out);
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------------------------------
 size_t rows_gpart_elems(long N) { return (size_t)((N + 63) / 64) * RW_GROW; }
 

@@ -229,8 +229,10 @@ int gp_acq_lp_argbest(gp_t *gp, int type, double par, double fmin, double y_mean
  * (tests/test_gpu_rows.py: 1e-9 on well-conditioned models, the north-star 1e-6 against the oracle everywhere); the
  * resident candidate block of gp_set_candidates is unspecified afterwards.
  *
- * gp_predict_rows = gp_predict(include_noise, mean[M], var[M]) and, when dmdx / dvdx are given (both or neither),
- *                   gp_predict_grad(dmdx[M, D], dvdx[M, D]).  mean / var may be NULL.  P = 1 layouts.
+ * gp_predict_rows = gp_predict(include_noise, mean[M], var[M]) and, when dmdx / dvdx are given,
+ *                   gp_predict_grad(dmdx[M, D], dvdx[M, D]).  mean / var may be NULL.  P = 1 layouts.  dmdx alone (dvdx,
+ *                   mean, var NULL) = gp_predict_grad(dmdx, NULL): the mean's gradient, one pass over the training points
+ *                   with no inverse factor behind it -- estimate_L's inner call (batch_local_penalization.py:55-67).
  * gp_acq_rows     = gp_acq / gp_acq_grad (lp = 0) or gp_acq_lp / gp_acq_lp_grad (lp = 1, with transform, Xb, nb, r_x0,
  *                   s_x0 as there): out[M], and dout[M, D] when given. */
 int gp_predict_rows(gp_t *gp, const double *Xs, int64_t M, int include_noise, double *mean, double *var, double *dmdx,

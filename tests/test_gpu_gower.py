@@ -91,7 +91,7 @@ def test_gower_estimate_L_and_table_batch(tag):
     a jacobian differentiates |d mean / dx| by forward differences of step 1e-8, so the end point amplifies relative
     differences of 1e-10 in the gradients to 1e-4..1e-2 of L, and of 1e-9 to 1e-1 (measured on the oracle itself:
     profiles/r05_estimate_L_sensitivity.txt).  Two float64 factorisations of a matrix with cond 1e7 differ by more than that,
-    so at noise 1e-6 the polished value is held to (i) the oracle's estimate_L code run on the DEVICE model -- identical,
+    so at noise 1e-6 the polished value is held to (i) the oracle's estimate_L code run on the DEVICE model -- 1e-6,
     which pins the host logic: stream, start, polish -- and (ii) L >= its start; at noise 1e-2 also to the fixture's L."""
     c = Case(G, tag)
     space = gpo.Design_space(DOMAIN)
@@ -107,7 +107,9 @@ def test_gower_estimate_L_and_table_batch(tag):
     L = gpo.estimate_L(gm.model, bounds)
     np.random.seed(int(c.np_seed))
     L_host = O.estimate_L(gm.model, bounds)             # the oracle's restatement driving the device model
-    assert L == L_host
+    # (the product asks the device for the mean's gradient alone, the restatement for both gradients: two kernels that add the
+    # same terms in another order -- last-bit differences, which the polish's forward differences amplify by ~1e7)
+    assert abs(L - L_host) <= 1e-6 * L_host
     assert L >= float(c.L_start) * (1 - TOL)
     if float(c.noise) >= 1e-4:
         assert abs(L - float(c.L)) <= 1e-3 * float(c.L), (L, float(c.L))

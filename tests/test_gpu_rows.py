@@ -191,9 +191,23 @@ def test_rows_route_state_and_errors():
     h.set_option("small_m", 8)
     with pytest.raises((ValueError, RuntimeError), match="M < 1"):
         _lib.check(h.lib, h.lib.gp_predict_rows(h.h, Xs.ctypes.data, 0, 1, None, None, None, None), "gp_predict_rows")
-    with pytest.raises((ValueError, RuntimeError), match="go together"):
-        dm1 = np.empty((1, 3))
-        _lib.check(h.lib, h.lib.gp_predict_rows(h.h, Xs.ctypes.data, 1, 1, None, None, dm1.ctypes.data, None), "gp_predict_rows")
+    with pytest.raises((ValueError, RuntimeError), match="dvdx needs dmdx"):
+        dv1 = np.empty((1, 3))
+        _lib.check(h.lib, h.lib.gp_predict_rows(h.h, Xs.ctypes.data, 1, 1, None, None, None, dv1.ctypes.data), "gp_predict_rows")
+    with pytest.raises((ValueError, RuntimeError), match="comes without mean"):
+        dm1, mu1 = np.empty((1, 3)), np.empty((1, 1))
+        _lib.check(h.lib, h.lib.gp_predict_rows(h.h, Xs.ctypes.data, 1, 1, mu1.ctypes.data, None, dm1.ctypes.data, None), "gp_predict_rows")
+    # the mean's gradient alone: no inverse factor is built for it, the values are the full call's
+    h.fit()
+    st0 = h.rows_stats()
+    h.profile(True)
+    for M in (1, 3, 8, 9):
+        jm = h.mean_grad_rows(Xs[:M])
+        assert not any(p["name"].startswith("potri") for p in h.phases())
+        h.set_candidates(Xs[:M])
+        _close(jm, h.predict_grad()[0], 1e-10)
+    h.profile(False)
+    assert h.rows_stats()["fused"] == st0["fused"] + 3 and h.rows_stats()["fallback"] == st0["fallback"] + 1
     with pytest.raises((ValueError, RuntimeError), match="unknown acquisition"):
         h.acq_rows(Xs[:1], 7, 0.0, 0.0)
     # bitwise repeatable (every partial sum has one writer and a fixed order)

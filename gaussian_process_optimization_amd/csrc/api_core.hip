@@ -447,6 +447,9 @@ extern "C" int gp_set_option(gp_t *g, const char *name, int64_t value) {
     } else if (!strcmp(name, "debug_potrf_lds")) {
         if (value < 0 || value > (1 << 20)) return fail(GP_ERR_ARG, "debug_potrf_lds out of range");
         potrf_set_debug_lds((int)value);   // process-wide test hook: forces refused diagonal-tile launches (tests/test_gpu_round4.py)
+    } else if (!strcmp(name, "debug_rows_skew")) {
+        // test hook: shifts the arrival base of the one-location path's next pass, so that no workgroup finishes it
+        g->rows_counter_base += (unsigned int)value;
     } else if (!strcmp(name, "rows_build")) {
         if (value < -1 || value > 1) return fail(GP_ERR_ARG, "rows_build out of range (-1: by rule, 0: never, 1: at the first call)");
         g->rows_build = (int)value;

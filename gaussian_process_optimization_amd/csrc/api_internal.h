@@ -118,7 +118,9 @@ struct gp_ctx {
     double *dRows = nullptr; // RowsWork partials
     long capRows = 0;
     unsigned int *dRowsCounter = nullptr;
-    double *hRowsOut = nullptr;          // pinned, device-visible result block of the fused path
+    double *hRowsOut = nullptr;          // pinned, device-visible result block of the fused path (+ the ticket behind it)
+    double rows_ticket = 0.0;            // counts the fused passes; the finishing workgroup writes it back
+    unsigned int rows_counter_base = 0;  // arrivals the counter holds from the passes before this one
     std::vector<double> lp_cache;        // local-penalisation batch as last uploaded (Xb | r | s), skipped when unchanged
     int lp_cache_nb = -1;
     long rows_fused_calls = 0, rows_fallback_calls = 0;

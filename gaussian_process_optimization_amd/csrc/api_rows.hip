@@ -41,9 +41,32 @@ static int rows_scratch(gp_ctx *g, RowsWork *w) {
         HIPCHK(hipMemsetAsync(g->dRowsCounter, 0, sizeof(unsigned int), g->s));
     }
     w->counter = g->dRowsCounter;
-    if (!g->hRowsOut)   // 3 MV (1 + D) doubles; coherent host memory the finish kernel writes and the host reads after the sync
-        HIPCHK(hipHostMalloc((void **)&g->hRowsOut, sizeof(double) * 3 * ROWS_MAX_M * (1 + GP_MAX_D), hipHostMallocDefault));
+    if (!g->hRowsOut) {   // 3 MV (1 + D) doubles + the ticket; coherent host memory the finish kernel writes and the host reads after the sync
+        HIPCHK(hipHostMalloc((void **)&g->hRowsOut, sizeof(double) * (ROWS_OUT_DOUBLES + 1), hipHostMallocDefault));
+        g->hRowsOut[ROWS_OUT_DOUBLES] = 0.0;
+    }
+    w->ticket = (g->rows_ticket += 1.0);
+    w->counter_base = g->rows_counter_base;
     return 0;
+}
+
+// One pass is on the stream: account for its arrivals, wait, and make sure it finished.  The finishing workgroup writes the pass's
+// ticket behind the results; if the stream reports an error or the ticket is not this pass's, a launch did not complete and the
+// arrival counter may hold anything: counter and base are cleared so that the next call starts clean, and this one fails loudly
+// instead of handing back the previous call's numbers.
+static int rows_wait(gp_ctx *g, RowsWork &w, unsigned finish_grid) {
+    g->rows_counter_base += finish_grid;
+    hipError_t e = hipStreamSynchronize(g->s);
+    int pending = gp_pending_error();
+    if (!pending && e == hipSuccess && g->hRowsOut[ROWS_OUT_DOUBLES] == w.ticket) return 0;
+    const std::string noted = pending ? gp_last_error() : std::string();
+    hipStreamSynchronize(g->s);
+    hipMemset(g->dRowsCounter, 0, sizeof(unsigned int));
+    g->rows_counter_base = 0;
+    if (pending) return fail(GP_ERR_HIP, "%s", noted.c_str());
+    if (e != hipSuccess) return fail(GP_ERR_HIP, "hipStreamSynchronize -> %s (one-location pass)", hipGetErrorString(e));
+    return fail(GP_ERR_HIP, "the one-location kernels did not complete (ticket %.0f, expected %.0f)", g->hRowsOut[ROWS_OUT_DOUBLES],
+                w.ticket);
 }
 
 // the penaliser's batch on the device; re-uploaded only when it changed (an L-BFGS run keeps one batch for hundreds of calls)
@@ -91,10 +114,14 @@ static int rows_fused(gp_ctx *g, const double *Xs, int M, int include_noise, int
         int ph = timed ? phase_begin(g, want_grad ? "rows_fused_grad" : "rows_fused", (want_grad ? 2.0 : 1.0) * (double)g->N * g->N * mc,
                                      (want_grad ? 2.0 : 1.0) * 8.0 * (double)g->N * g->N / 2)
                        : -1;
+        if (m0 > 0) {
+            w.ticket = (g->rows_ticket += 1.0);
+            w.counter_base = g->rows_counter_base;
+        }
         launch_rows(g->s, g->dLi, g->Npad, rx, g->kp, g->dX, g->N, g->dAlpha, want_grad, g->kp.variance,
                     include_noise ? g->noise : 0.0, aq, w, g->hRowsOut, g->rows_nt < 0 ? (g->Npad > 8192 ? 1 : 0) : g->rows_nt);
         if (timed) phase_end(g, ph);
-        GP_SYNC(g->s);
+        if ((rc = rows_wait(g, w, (unsigned)((g->N + 63) / 64)))) return rc;
         const double *o = g->hRowsOut;
         for (int m = 0; m < mc; ++m) {
             if (mean) mean[m0 + m] = o[m];
@@ -133,8 +160,12 @@ extern "C" int gp_predict_rows(gp_t *g, const double *Xs, int64_t M, int include
                 RowsX rx;
                 rx.M = mc;
                 memcpy(rx.xs, Xs + (long)m0 * g->D, sizeof(double) * mc * g->D);
+                if (m0 > 0) {
+                    w.ticket = (g->rows_ticket += 1.0);
+                    w.counter_base = g->rows_counter_base;
+                }
                 launch_rows_mean_grad(g->s, rx, g->kp, g->dX, g->N, g->dAlpha, w, g->hRowsOut);
-                GP_SYNC(g->s);
+                if ((rc = rows_wait(g, w, (unsigned)((g->N + 255) / 256)))) return rc;
                 memcpy(dmdx + (long)m0 * g->D, g->hRowsOut + 3 * MV, sizeof(double) * mc * g->D);
             }
             ++g->rows_fused_calls;

@@ -201,9 +201,13 @@ struct RowsAcq {
     int lp, transform, nb;    // local penalisation (LP.py): on / log transform / batch size
     const double *Xb, *r0, *s0;
 };
+#define ROWS_OUT_DOUBLES (3 * ROWS_MAX_M * (1 + GP_MAX_D))   // result block; one more double behind it carries the call's ticket
 struct RowsWork {             // device scratch (api_rows.hip sizes it): every partial has one writer
     double *wpart, *bpart, *meanpart, *vpart, *gpart;
-    unsigned int *counter;
+    unsigned int *counter;    // arrival counter of the finishing kernels: never reset between calls, each pass counts from its own base
+    unsigned int counter_base;
+    double ticket;            // written behind the results by the workgroup that finishes the call: the host checks it (a launch that
+                              // did not complete must not leave the previous call's numbers in the block)
 };
 long rows_tiles(int nt);
 int rows_block_height(int nt);   // rows of the tile per workgroup: 32 for matrices of a few tiles, else 128

@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256) void rows_backward_kernel(const double *Li, lo
 // w_m[n] = sum_C wpart[C][m][n] for |w|^2 (value call) -- wave v takes every fourth partial, the four sums are added in wave
 // order.  Wave 0 then takes point n through the two gradients_X sums (the geometry of predict_grad_kernel in grad.hip: Euclidean
 // scaled differences on the kernel's own lengthscale -- under Gower too, as the fork does, stationary.py:336-364).  Per-workgroup
-// sums go to gpart, and the LAST workgroup to arrive (device-scope counter) reduces them in workgroup order -- eight interleaved
-// slices, added in slice order -- and writes the results.
+// sums go to gpart, and the LAST workgroup to arrive (device-scope counter, counted from this pass's base: it is never reset, so a
+// pass cannot inherit a stale count) reduces them in workgroup order -- eight interleaved slices, added in slice order -- and
+// writes the results, then the pass's ticket behind them.
 // gpart row (per workgroup): [2 M D gradient sums | M sums of w^2], RW_GROW doubles apart
 // out (host-visible): [mean MV][var MV][acq MV][dmdx MV D][dvdx MV D][dacq MV D]
 #define RW_GROW (2 * ROWS_MAX_XS + ROWS_MAX_M)
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(RowsX rx, KernParams k
                                                           const double *wpart, const double *bpart, const double *meanpart,
                                                           const double *vpart, long Npad, int nt, int rbh, int want_grad,
                                                           double kss, double noise_add, RowsAcq aq, double *gpart,
-                                                          unsigned int *counter, double *out) {
+                                                          unsigned int *counter, unsigned int counter_base, double *out,
+                                                          double ticket) {
     __shared__ double xs_s[ROWS_MAX_XS], xraw_s[ROWS_MAX_XS];
     __shared__ double part_s[4][MV][64];
     __shared__ double fin_s[8][RW_GROW + 2 * ROWS_MAX_M];
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(RowsX rx, KernParams k
     }
     __threadfence();
     __syncthreads();
-    if (tid == 0) last_s = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (tid == 0) last_s = (atomicAdd(counter, 1u) - counter_base == gridDim.x - 1) ? 1 : 0;   // (unsigned: wraps with the base)
     __syncthreads();
     if (!last_s) return;
     __threadfence();
@@ -373,7 +375,8 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(RowsX rx, KernParams k
             out[2 * MV + m] = neg;
         }
     }
-    if (tid == 0) *counter = 0u;   // ready for the next call (stream-ordered behind this kernel)
+    __syncthreads();
+    if (tid == 0) out[ROWS_OUT_DOUBLES] = ticket;   // this pass is complete (the host checks the ticket behind the results)
 }
 
 // ---- the mean's gradient alone ---------------------------------------------------------------------------------------------------------
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(RowsX rx, KernParams k
 // sums in workgroup order and writes dmdx [M, D] at out + 3 MV (the place rows_finish_kernel writes it).
 template <int MV>
 __global__ __launch_bounds__(256) void rows_mean_grad_kernel(RowsX rx, KernParams kp, const double *X, long N, const double *alpha,
-                                                             double *gpart, unsigned int *counter, double *out) {
+                                                             double *gpart, unsigned int *counter, unsigned int counter_base,
+                                                             double *out, double ticket) {
     __shared__ double xs_s[ROWS_MAX_XS];
     __shared__ double sh[4][ROWS_MAX_XS];
     __shared__ double fin_s[8][ROWS_MAX_XS];
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(256) void rows_mean_grad_kernel(RowsX rx, KernParam
     if (tid < nval) gpart[(long)blockIdx.x * RW_GROW + tid] = ((sh[0][tid] + sh[1][tid]) + sh[2][tid]) + sh[3][tid];
     __threadfence();
     __syncthreads();
-    if (tid == 0) last_s = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (tid == 0) last_s = (atomicAdd(counter, 1u) - counter_base == gridDim.x - 1) ? 1 : 0;   // (unsigned: wraps with the base)
     __syncthreads();
     if (!last_s) return;
     __threadfence();
@@ -428,18 +432,19 @@ __global__ __launch_bounds__(256) void rows_mean_grad_kernel(RowsX rx, KernParam
     for (int v = tid; v < nval; v += 256) {
         double s = 0.0;
         for (int j = 0; j < 8; ++j) s += fin_s[j][v];
-        out[3 * MV + (v / D) * D + v % D] = s / kp.ls[v % D];   // (x - x') / l^2 = scaled difference / l
+        out[3 * MV + v] = s / kp.ls[v % D];   // (x - x') / l^2 = scaled difference / l
     }
-    if (tid == 0) *counter = 0u;
+    __syncthreads();
+    if (tid == 0) out[ROWS_OUT_DOUBLES] = ticket;
 }
 
 void launch_rows_mean_grad(hipStream_t s, const RowsX &rx, const KernParams &kp, const double *X, long N, const double *alpha,
                            const RowsWork &w, double *out) {
     const unsigned grid = (unsigned)((N + 255) / 256);
     if (rx.M == 1)
-        GP_LAUNCH(rows_mean_grad_kernel<1>, dim3(grid), dim3(256), 0, s, rx, kp, X, N, alpha, w.gpart, w.counter, out);
+        GP_LAUNCH(rows_mean_grad_kernel<1>, dim3(grid), dim3(256), 0, s, rx, kp, X, N, alpha, w.gpart, w.counter, w.counter_base, out, w.ticket);
     else
-        GP_LAUNCH(rows_mean_grad_kernel<ROWS_MAX_M>, dim3(grid), dim3(256), 0, s, rx, kp, X, N, alpha, w.gpart, w.counter, out);
+        GP_LAUNCH(rows_mean_grad_kernel<ROWS_MAX_M>, dim3(grid), dim3(256), 0, s, rx, kp, X, N, alpha, w.gpart, w.counter, w.counter_base, out, w.ticket);
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------------------------
@@ -458,7 +463,7 @@ static void launch_rows_t(hipStream_t s, const double *Li, long Npad, const Rows
     if (want_grad)
         GP_LAUNCH((rows_backward_kernel<MV, RB, NT>), dim3(tiles), dim3(256), 0, s, Li, Npad, w.wpart, Npad, rx.M, w.bpart, w.vpart);
     GP_LAUNCH(rows_finish_kernel<MV>, dim3(fin), dim3(256), 0, s, rx, kp, X, N, alpha, w.wpart, w.bpart, w.meanpart, w.vpart, Npad, nt,
-              RB, want_grad, kss, noise_add, aq, w.gpart, w.counter, out);
+              RB, want_grad, kss, noise_add, aq, w.gpart, w.counter, w.counter_base, out, w.ticket);
 }
 
 void launch_rows(hipStream_t s, const double *Li, long Npad, const RowsX &rx, const KernParams &kp, const double *X, long N,

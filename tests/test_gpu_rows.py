@@ -328,3 +328,22 @@ def test_inverse_factor_is_built_by_the_ski_rental_rule():
     assert abs(a.item() + a0.item()) <= 1e-5 * max(abs(a0.item()), 1e-12)
     np.testing.assert_allclose(da, -da0, rtol=0, atol=1e-5 * max(np.max(np.abs(da0)), 1e-12))
     h.close()
+
+
+def test_a_pass_that_nobody_finishes_is_an_error_not_a_stale_result():
+    """The finishing workgroup of a one-location pass writes the pass's ticket behind the results; the host checks it after the
+    sync.  With the arrival base skewed (test hook) no workgroup finishes: the call raises instead of returning the previous
+    call's numbers, the counter is cleared, and the next call is right again."""
+    h, X, Y, Xs, ls = _fitted(600, 3, _lib.GP_KERNEL_RBF, False, 1e-2, seed=21)
+    fmin = h.fmin()
+    good = h.acq_rows(Xs[:1], _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+    other = h.acq_rows(Xs[1:2], _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+    assert not np.array_equal(good[0], other[0])
+    for call in (lambda: h.acq_rows(Xs[:1], _lib.GP_ACQ_EI, 0.01, fmin, grad=True), lambda: h.predict_rows(Xs[:1], True),
+                 lambda: h.mean_grad_rows(Xs[:1])):
+        h.set_option("debug_rows_skew", 3)
+        with pytest.raises(RuntimeError, match="did not complete"):
+            call()
+        again = h.acq_rows(Xs[:1], _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+        assert np.array_equal(again[0], good[0]) and np.array_equal(again[1], good[1])
+    h.close()

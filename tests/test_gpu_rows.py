@@ -37,13 +37,16 @@ def _fitted(N, D, kernel, ard, noise, seed):
 
 
 @pytest.mark.parametrize("N,D,kernel,ard", [(100, 2, _lib.GP_KERNEL_RBF, False), (512, 8, _lib.GP_KERNEL_RBF, False),
+                                            (128, 1, _lib.GP_KERNEL_MATERN52, False), (2048, 4, _lib.GP_KERNEL_RBF, False),
+                                            (2049, 7, _lib.GP_KERNEL_MATERN52, True),
                                             (1100, 3, _lib.GP_KERNEL_MATERN52, True), (2200, 5, _lib.GP_KERNEL_MATERN52, False),
                                             (4500, 16, _lib.GP_KERNEL_RBF, True)])
 @pytest.mark.parametrize("noise", [1e-2, 1e-6])
 def test_rows_calls_equal_the_batched_calls(N, D, kernel, ard, noise):
     """gp_predict_rows / gp_acq_rows for M = 1 .. 8 (fused: one pass for M <= 4, two beyond) and M = 9 (the batched calls
     inside) against gp_set_candidates + gp_predict / gp_predict_grad / gp_acq_grad / gp_acq_lp_grad.  Sizes cover one row
-    block (N = 100), exactly one chunk, two chunks with a cut last one (N = 1100: 9 row blocks), and 36 row blocks."""
+    block (N = 100, 128), exactly one chunk, two chunks with a cut last one (N = 1100: 9 row blocks), the last size with 32-row
+    workgroups and the first with 128-row ones (N = 2048 / 2049: 16 / 17 tiles), and 36 row blocks."""
     h, X, Y, Xs, ls = _fitted(N, D, kernel, ard, noise, seed=N)
     h.set_option("rows_build", 1)          # compare the fused path at every size (the default rule rents the first calls above N = 4096)
     Xs = Xs.copy()

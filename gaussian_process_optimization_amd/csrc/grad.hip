@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *X, lon
     for (int q = 0; q < NACC; ++q) acc[q] = 0.0;
     const int cx = (tid & 63) * 2, ry = tid >> 6;
     const long gc = (long)tn * GP_TILE + cx;
-    for (int q4 = 0; q4 < 32; ++q4) {
+    // gridDim.y workgroups share a tile (few tiles: the launch is latency-bound, a quarter of the rows each): q4 in [q_lo, q_hi)
+    const int q_per = 32 / (int)gridDim.y, q_lo = (int)blockIdx.y * q_per, q_hi = q_lo + q_per;
+    for (int q4 = q_lo; q4 < q_hi; ++q4) {
         const int r = ry + 4 * q4;
         const long gr = (long)tm * GP_TILE + r;
         if (gr >= N) continue;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *X, lon
         if (lane == 0) red[wv][q] = v;
     }
     __syncthreads();
-    if (tid < NACC) partial[t * NACC + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid < NACC) partial[(t * gridDim.y + blockIdx.y) * NACC + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const double *partial, long ntile, int nacc, double *out) {
@@ -219,9 +221,12 @@ void launch_lml_grad(hipStream_t s, const double *X, long N, long Npad, const Ke
     const int nt = (int)(Npad / GP_TILE);
     const long ntile = (long)nt * (nt + 1) / 2;
     const size_t shm = ((size_t)(kp.gower ? 4 : 2) * kp.D * GP_TILE + (size_t)2 * P * GP_TILE) * sizeof(double);
-    GP_LAUNCH(lml_grad_tile_kernel, dim3((unsigned)ntile), dim3(256), shm, s, X, N, kp, ard, d0, alpha, Npad,
+    // few tiles (N <= ~2900): four workgroups per tile, 32 rows each -- 6 workgroups of 128 x 128 covariance evaluations were a
+    // quarter of an LML + gradient evaluation at N = 300; the partial sums are added per (tile, quarter) in the same fixed order
+    const unsigned split = ntile < 256 ? 4u : 1u;
+    GP_LAUNCH(lml_grad_tile_kernel, dim3((unsigned)ntile, split), dim3(256), shm, s, X, N, kp, ard, d0, alpha, Npad,
                        P, Wi, ldw, partial);
-    GP_LAUNCH(sum_partials_kernel, dim3(NACC), dim3(1024), 0, s, partial, ntile, NACC, out);
+    GP_LAUNCH(sum_partials_kernel, dim3(NACC), dim3(1024), 0, s, partial, ntile * split, NACC, out);
 }
 
 // ---- predictive gradients (gp.py:407-454) ----------------------------------------------------------

@@ -115,9 +115,12 @@ class GPRegression(Parameterized):
             self.normalizer = normalizer
         self.Y_metadata = Y_metadata
         self.max_jitter_tries = 5  # jitchol default, linalg.py:56
-        # hyper-parameter search of a Gower model: 'differences' of the device LML (default), or 'fork' = the fork's own
-        # update_gradients_full values (stationary.py:218-238 on a Gower K: not derivatives of the objective)
-        self.gower_gradients = 'differences' 
+        # hyper-parameter search of a Gower model.  'exact' (default): the LML's true gradient from ONE device call -- the Gower
+        # K is variance^D times a product that depends on neither hyper-parameter, so d LML / d variance = D x the fork's
+        # variance entry and d LML / d lengthscale = 0 (stationary.py:116-135); 'differences': forward differences of the
+        # device LML (the same numbers, D + 2 fits per evaluation); 'fork': the fork's own update_gradients_full values
+        # (stationary.py:218-238 on a Gower K: not derivatives of the objective -- what the reference's optimiser follows)
+        self.gower_gradients = 'exact'
         self._h = _lib.Handle(device)
         self._groups = {}        # replica groups over several devices, keyed by the device tuple (_device_group)
         self._data_epoch = 0
@@ -241,6 +244,9 @@ class GPRegression(Parameterized):
         else:
             self._ensure_fit()
             dv, dl, dn = self._h.lml_grad(nls)
+        if self._uses_gower() and self.gower_gradients != 'fork':
+            # the device returns the fork's values; the LML's own: K = variance^D x (a product free of both parameters)
+            dv, dl = dv * self.kern.input_dim, np.zeros_like(dl)
         self.kern.variance.gradient = np.atleast_1d(dv)
         self.kern.lengthscale.gradient = dl
         self.likelihood.variance.gradient = np.atleast_1d(dn)
@@ -410,12 +416,11 @@ class GPRegression(Parameterized):
     def _obj_grad(self, x):
         try:
             self.optimizer_array = x
-            if not self._uses_gower() or self.gower_gradients == 'fork':
+            if not self._uses_gower() or self.gower_gradients in ('fork', 'exact'):
                 g = self.objective_function_gradients()   # gp_fit_grad: leaves the LML of this x behind
                 return self.objective_function(), g
-            # Gower kernel: the fork pairs the Gower K with Euclidean gradient formulas (stationary.py:218-238), which
-            # are not gradients of this objective (gp_lml_grad returns them all the same: ``gower_gradients = 'fork'``
-            # follows the reference's optimiser); by default forward differences of the device LML are used instead
+            # 'differences': forward differences of the device LML (the Gower K paired with the fork's Euclidean gradient
+            # formulas, stationary.py:218-238, is not differentiated by them)
             f = self.objective_function()
             g = np.empty_like(x)
             for i in range(x.size):

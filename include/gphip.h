@@ -81,8 +81,9 @@ int gp_set_params(gp_t *gp, int kernel, int ard, double variance, const double *
  * K(Xs, X) inside dv/dx (gp.py:451-452) -- what run.py:1206-1225,1244 runs L-BFGS and estimate_L on.  gp_lml_grad and
  * gp_fit_grad likewise return what the fork's update_gradients_full computes (stationary.py:218-238): the Gower K as the
  * weight of the variance gradient, Euclidean dK/dr on the kernel's own lengthscale in the lengthscale gradients.  Those
- * are NOT derivatives of the Gower model's LML (K does not depend on that lengthscale at all); the host layer optimises
- * a Gower model on differences of the device LML unless told to follow the fork (GPRegression.gower_gradients). */
+ * are NOT derivatives of the Gower model's LML (K does not depend on that lengthscale at all, and depends on the variance
+ * as variance^D); the host layer derives the true gradient from them (D x the variance entry, 0 for the lengthscale) unless
+ * told to follow the fork (GPRegression.gower_gradients). */
 int gp_set_gower(gp_t *gp, int enable, const int *is_discrete, const double *range);
 
 /* ---- fit ---------------------------------------------------------------

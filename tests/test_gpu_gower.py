@@ -193,8 +193,9 @@ def test_gower_front_door_as_run_py_calls_it():
 def test_gower_hyper_gradients_are_the_forks(tag):
     """gp_lml_grad of a Gower model == the fork's update_gradients_full (stationary.py:218-238 restated in the oracle): the
     Gower K weighs the variance gradient, the Euclidean dK/dr on the kernel's own lengthscale makes the lengthscale gradient
-    -- although K does not depend on that lengthscale at all.  The host therefore optimises on differences of the device
-    LML by default (must not lower it); `gower_gradients = 'fork'` follows the reference's optimiser instead."""
+    -- although K does not depend on that lengthscale at all.  The host therefore optimises on the LML's true gradient by default
+    (one device call: D x the fork's variance entry, zero for the lengthscale; == differences of the device LML);
+    `gower_gradients = 'fork'` follows the reference's optimiser instead."""
     c = Case(G, tag)
     space = gpo.Design_space(DOMAIN)
     m = _model(c, space)
@@ -211,6 +212,19 @@ def test_gower_hyper_gradients_are_the_forks(tag):
     m.kern.lengthscale[:] = float(c.lengthscale[0]) * 1.5
     assert abs(m.log_likelihood() - l0) <= 1e-9 * abs(l0) and np.max(np.abs(dl0)) > 0
     m.kern.lengthscale[:] = float(c.lengthscale[0])
+    # the host's default: the LML's TRUE gradient from the same device call (D x the fork's variance entry, 0 for the
+    # lengthscale) == forward differences of the device LML, and the model's own checkgrad passes with it
+    assert m.gower_gradients == 'exact'
+    x = m.optimizer_array.copy()
+    f_exact, g_exact = m._obj_grad(x)
+    m.gower_gradients = 'differences'
+    f_diff, g_diff = m._obj_grad(x)
+    m.gower_gradients = 'exact'
+    assert f_exact == f_diff
+    np.testing.assert_allclose(g_exact, g_diff, rtol=0, atol=2e-4 * max(1.0, np.max(np.abs(g_exact))))
+    if float(c.noise) >= 1e-4:
+        np.random.seed(1)
+        assert m.checkgrad()
     if "_N64_" in tag:
         l0 = m.log_likelihood()
         m.optimize(max_iters=10)

@@ -1,4 +1,6 @@
-// A handful of candidates at a time: the calls the acquisition optimiser makes between two fits.
+// A handful of candidates at a time BY SUBSTITUTION against L: the route of gp_set_candidates + gp_predict / gp_predict_grad /
+// gp_acq_grad with M <= "small_m" resident rows, and of the one-call entry points (gp_*_rows, api_rows.hip) while the inverse factor
+// of the fused path (onerow.hip) does not exist yet -- the first N / 768 calls after a fit above N = 4096.
 //
 // scipy's L-BFGS-B asks for ONE row per call (GPyOpt/GPyOpt/optimization/optimizer.py:28-61 -> models/gpmodel.py:131-142 ->
 // GPy/GPy/core/gp.py:407-454, posterior.py:273-302), hundreds of times per BO iteration.  Through the tile path such a call pads
@@ -8,7 +10,8 @@
 //
 //   forward substitution  w = L^-1 k*  by panels, with the inverted diagonal panels invP_J the fit already built:
 //       w_J = invP_J t_J ;   t_r -= L[r, J] . w_J   for every row r below the panel
-//   (dtrtrs, posterior.py:294) and, for the gradients, beta = Ky^-1 k* as row dots with the symmetric Ky^-1 (gp.py:451-452).
+//   (dtrtrs, posterior.py:294) and, for the gradients, beta = Ky^-1 k* -- as row dots with the symmetric Ky^-1 when it exists
+//   (gp.py:451-452), else by the backward substitution of the alpha solve (api_grad.hip, run_predict_grad).
 //
 // Both are ROW DOTS of a row-major matrix with up to four vectors at once -- one kernel, rowdot_kernel: a wave takes one matrix
 // row at a time, lane l the elements 2 l, 2 l + 1 (+ 128 q) of the chunk (1 KB per wave instruction, fully coalesced), the

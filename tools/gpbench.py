@@ -982,6 +982,70 @@ def lp_driver_timing():
             bo.model.model.close()
 
 
+@command
+def rows_fuzz():
+    """Random sweep of the one-location entry points against the batched ones: N, D, M, kernel, ARD, Gower, noise, variance drawn at
+    random (test tooling).  usage: rows_fuzz [draws]"""
+    import json
+    import numpy as np
+    from gaussian_process_optimization_amd import _lib
+    draws = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    rng = np.random.default_rng(2025)
+    h = _lib.Handle(0)
+    h.set_option("emulate_fp64", 0)
+    h.set_option("rows_build", 1)
+    worst = {"mean": 0.0, "var": 0.0, "dm": 0.0, "dv": 0.0, "acq": 0.0, "dacq": 0.0}
+    bad = []
+    for it in range(draws):
+        N = int(rng.choice([1, 2, 5, 31, 32, 33, 64, 127, 128, 129, 255, 257, 500, 1023, 1024, 1025, 1500, 2047, 2048, 2049, 2600, 3100]))
+        D = int(rng.choice([1, 2, 3, 6, 8, 16, 31, 64]))
+        M = int(rng.integers(1, 9))
+        kern = int(rng.integers(2)); ard = int(rng.integers(2)); gower = int(rng.integers(3) == 0)
+        noise = float(rng.choice([1e-1, 1e-2, 1e-3])); var = float(rng.uniform(0.4, 2.0))
+        X = rng.uniform(0, 1, (N, D))
+        if gower:
+            disc = rng.integers(0, 2, D)
+            X[:, disc == 1] = np.round(X[:, disc == 1] * 3)
+        Y = rng.standard_normal((N, 1))
+        Xs = rng.uniform(-0.1, 1.1, (M, D))
+        if gower:
+            Xs[:, disc == 1] = np.round(np.clip(Xs[:, disc == 1], 0, 1) * 3)
+        if N >= M and rng.integers(2):
+            Xs[0] = X[int(rng.integers(N))]
+        ls = rng.uniform(0.3, 1.5, D) * np.sqrt(D) * 0.5 if ard else np.array([0.35 * np.sqrt(D)])
+        h.set_data(X, Y)
+        h.set_params(kern, ard, var, ls, noise)
+        if gower:
+            h.set_gower(disc.astype(np.int32), np.where(disc == 1, 1.0, 1.2))
+        else:
+            h.set_gower()
+        h.fit()
+        fmin = h.fmin()
+        h.set_candidates(Xs)
+        mu_b, v_b = h.predict(True)
+        dm_b, dv_b = h.predict_grad()
+        a_b, da_b = h.acq_grad(_lib.GP_ACQ_EI, 0.01, fmin)
+        mu, v, dm, dv = h.predict_rows(Xs, True, grad=True)
+        a, da = h.acq_rows(Xs, _lib.GP_ACQ_EI, 0.01, fmin, grad=True)
+        jm = h.mean_grad_rows(Xs)
+
+        def rel(x, y, floor=1e-300):
+            return float(np.max(np.abs(np.asarray(x) - np.asarray(y))) / max(float(np.max(np.abs(y))), floor))
+        errs = {"mean": rel(mu, mu_b, 1e-6), "var": float(np.max(np.abs(v - v_b) / np.maximum(np.abs(v_b), 1e-12))),
+                "dm": max(rel(dm, dm_b, 1e-6), rel(jm, dm_b, 1e-6)), "dv": rel(dv, dv_b, 1e-6), "acq": rel(a, a_b, 1e-12),
+                "dacq": rel(da, da_b, 1e-12)}
+        finite = all(np.all(np.isfinite(z)) == np.all(np.isfinite(zb)) for z, zb in ((mu, mu_b), (v, v_b), (dm, dm_b), (dv, dv_b)))
+        for k, e in errs.items():
+            if np.isfinite(e):
+                worst[k] = max(worst[k], e)
+        if not finite or errs["mean"] > 1e-8 or errs["var"] > 1e-7 or errs["dm"] > 1e-8 or errs["dv"] > 1e-6 or errs["acq"] > 1e-6 or errs["dacq"] > 1e-5:
+            bad.append({"draw": it, "N": N, "D": D, "M": M, "kernel": kern, "ard": ard, "gower": gower, "noise": noise, **errs})
+    st = h.rows_stats()
+    print(json.dumps({"draws": draws, "worst_relative_difference_to_the_batched_calls": worst, "outside_tolerance": bad,
+                      "fused_calls": st["fused"], "fallback_calls": st["fallback"]}, indent=1))
+    h.close()
+
+
 def main():
     if len(sys.argv) < 2 or sys.argv[1] in ("-h", "--help", "--list"):
         print(__doc__)

@@ -209,6 +209,17 @@ class Handle(object):
             raise ValueError("lengthscale has %d entries, expected %d" % (ls.size, self.D if ard else 1))
         check(self.lib, self.lib.gp_set_params(self.h, int(kernel), int(bool(ard)), float(variance), dptr(ls),
                                                float(noise)), "gp_set_params")
+        self.n_ls = ls.size
+
+    def _grad_ls(self, nls):
+        """The lengthscale-gradient buffer for gp_lml_grad / gp_fit_grad: the library writes one entry per lengthscale of the
+        LAST gp_set_params (1, or D with ard) whatever the caller expects, so a wrong count is refused here."""
+        want = getattr(self, "n_ls", None)
+        if want is None:
+            raise ValueError("set_params has not been called on this handle")
+        if int(nls) != want:
+            raise ValueError("the model has %d lengthscale(s), the caller asked for %d gradient entries" % (want, int(nls)))
+        return np.empty(want)
 
     def set_gower(self, is_discrete=None, ranges=None):
         """Enable (or, with no arguments, disable) the fork's Gower product kernel."""
@@ -241,7 +252,7 @@ class Handle(object):
         """gp_fit + gp_lml_grad as one call: ((lml, logdet, jitter), (dvariance, dlengthscale[nls], dnoise))."""
         lml, logdet, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         dv, dn = ctypes.c_double(), ctypes.c_double()
-        dl = np.empty(nls)
+        dl = self._grad_ls(nls)
         rc = self.lib.gp_fit_grad(self.h, int(maxtries), ctypes.byref(lml), ctypes.byref(logdet), ctypes.byref(jit),
                                   ctypes.byref(dv), dptr(dl), ctypes.byref(dn))
         check(self.lib, rc, "gp_fit_grad")
@@ -311,7 +322,7 @@ class Handle(object):
 
     def lml_grad(self, nls):
         dv, dn = ctypes.c_double(), ctypes.c_double()
-        dl = np.empty(nls)
+        dl = self._grad_ls(nls)
         check(self.lib, self.lib.gp_lml_grad(self.h, ctypes.byref(dv), dptr(dl), ctypes.byref(dn)), "gp_lml_grad")
         return dv.value, dl, dn.value
 

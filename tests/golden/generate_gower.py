@@ -35,7 +35,9 @@ DOMAIN = [{'name': 'motor', 'type': 'discrete', 'domain': tuple(range(6))},
 # (N, M, seed, kernel variance).  Under Gower the diagonal of K is variance^6 while Kdiag stays variance
 # (stationary.py:131-133 against :195-198), so variance > 1 drives the predictive variance negative and GPModel's clip to
 # 1e-10 (gpmodel.py:99) takes over nearly everywhere: the third case keeps that regime (ties, EI = 0, 0 * inf gradients).
-CASES = [(64, 48, 0, 1.0), (300, 120, 1, 0.8), (150, 60, 2, 1.25)]
+CASES = [(64, 48, 0, 1.0), (300, 120, 1, 0.8), (150, 60, 2, 1.25), (100, 40, 3, 0.9)]
+ARD_SEEDS = (3,)          # the last case carries one Euclidean lengthscale per variable (ARD=True): under Gower they enter the gradient
+                          # formulas only (stationary.py:188-191,336-364), K ignores them
 KERNELS = ["Mat52", "rbf"]                    # GPyOpt's default kernel first (gpmodel.py:58)
 NOISES = [1e-6, 1e-2]                         # exact_feval=True (gpmodel.py:72-73) first
 BATCH, TABLE = 5, 2000
@@ -53,8 +55,9 @@ def make_case(space, mixed, N, M, seed, variance, kname, noise):
     Xs[:4] = X[:4]                                    # candidates ON training rows: every factor at r = 0
     Xs[4:8, :4] = X[4:8, :4]                          # same levels, other continuous values
     Y = O.normalize(objective(X) + 0.02 * rng.standard_normal((N, 1)))   # bo.py:236-254, normalize_Y=True
-    ls = np.array([1.0 + 0.5 * seed])                 # the kernel's own (Euclidean) lengthscale parameter
-    kern = O.make_kernel(kname, 6, variance, ls, Gower=True, space=space)
+    ard = seed in ARD_SEEDS
+    ls = (0.6 + 0.35 * np.arange(6)) if ard else np.array([1.0 + 0.5 * seed])   # the kernel's own (Euclidean) lengthscale parameter(s)
+    kern = O.make_kernel(kname, 6, variance, ls, ARD=ard, Gower=True, space=space)
     gp = O.OracleGP(X, Y, kern, noise)
     gm = O.OracleGPModel(gp)
     post = gp.posterior
@@ -65,7 +68,7 @@ def make_case(space, mixed, N, M, seed, variance, kname, noise):
     ei, dei = O.acq_EI_withGradients(gm, Xs, 0.01, fmin)
     lcb, dlcb = O.acq_LCB_withGradients(gm, Xs, 2.0)
     mpi, dmpi = O.acq_MPI_withGradients(gm, Xs, 0.01, fmin)
-    out = dict(X=X, Y=Y, Xs=Xs, variance=variance, lengthscale=ls, noise=noise, kernel=0 if kname == "rbf" else 1,
+    out = dict(X=X, Y=Y, Xs=Xs, variance=variance, lengthscale=ls, ard=int(ard), noise=noise, kernel=0 if kname == "rbf" else 1,
                rows=rows, K_rows=post["K"][rows], Kx_rows=kern.K(Xs, X)[:8], lml=post["lml"], logdet=post["logdet"],
                alpha=post["alpha"], mu=mu, var=var, dmdx=dmdx, dvdx=dvdx, fmin=fmin,
                neg_EI=-ei, neg_dEI=-dei, neg_LCB=-lcb, neg_dLCB=-dlcb, neg_MPI=-mpi, neg_dMPI=-dmpi)

@@ -34,14 +34,14 @@ TOL = 1e-6
 
 def _model(c, space):
     cls = gpo.kern.RBF if int(c.kernel) == 0 else gpo.kern.Matern52
-    k = cls(6, variance=float(c.variance), lengthscale=c.lengthscale, Gower=True, space=space)
+    k = cls(6, variance=float(c.variance), lengthscale=c.lengthscale, ARD=bool(int(c.ard)), Gower=True, space=space)
     return gpo.models.GPRegression(c.X, c.Y, k, noise_var=float(c.noise))
 
 
 def _gpmodel(c, space):
     """GPModel around the fixture's hyper-parameters (no optimisation), noise as given."""
     cls = gpo.kern.RBF if int(c.kernel) == 0 else gpo.kern.Matern52
-    k = cls(6, variance=float(c.variance), lengthscale=c.lengthscale, Gower=True, space=space)
+    k = cls(6, variance=float(c.variance), lengthscale=c.lengthscale, ARD=bool(int(c.ard)), Gower=True, space=space)
     gm = gpo.GPModel(kernel=k, noise_var=float(c.noise), max_iters=0, Gower=True, space=space, verbose=False)
     gm.updateModel(c.X, c.Y, None, None)
     return gm
@@ -189,7 +189,7 @@ def test_gower_front_door_as_run_py_calls_it():
     bo.model.model.close()
 
 
-@pytest.mark.parametrize("tag", [t for t in TAGS if "_N64_" in t or "_N300_" in t])
+@pytest.mark.parametrize("tag", [t for t in TAGS if "_N64_" in t or "_N300_" in t or "_N100_" in t])
 def test_gower_hyper_gradients_are_the_forks(tag):
     """gp_lml_grad of a Gower model == the fork's update_gradients_full (stationary.py:218-238 restated in the oracle): the
     Gower K weighs the variance gradient, the Euclidean dK/dr on the kernel's own lengthscale makes the lengthscale gradient
@@ -199,19 +199,21 @@ def test_gower_hyper_gradients_are_the_forks(tag):
     c = Case(G, tag)
     space = gpo.Design_space(DOMAIN)
     m = _model(c, space)
-    kern0 = O.make_kernel("rbf" if int(c.kernel) == 0 else "Mat52", 6, float(c.variance), c.lengthscale, Gower=True,
-                          space=O.MixedSpace(DOMAIN))
+    kern0 = O.make_kernel("rbf" if int(c.kernel) == 0 else "Mat52", 6, float(c.variance), c.lengthscale, ARD=bool(int(c.ard)),
+                          Gower=True, space=O.MixedSpace(DOMAIN))
     dv0, dl0, dn0 = O.OracleGP(c.X, c.Y, kern0, float(c.noise)).gradients()
     m.log_likelihood()
-    dv, dl, dn = m._h.lml_grad(1)
+    dv, dl, dn = m._h.lml_grad(np.asarray(c.lengthscale).size)
+    with pytest.raises(ValueError):                    # the library writes one entry per lengthscale: a shorter buffer is refused
+        m._h.lml_grad(np.asarray(c.lengthscale).size + 1)
     scale = max(abs(dv0), float(np.max(np.abs(dl0))), abs(dn0), 1.0)
     tol = TOL if float(c.noise) >= 1e-4 else 1e-4      # Ky^-1 enters with 1 / noise: cond * eps on both float64 paths
     assert abs(dv - dv0) <= tol * scale and np.max(np.abs(dl - dl0)) <= tol * scale and abs(dn - dn0) <= tol * max(abs(dn0), 1.0)
     # the lengthscale gradient is not a derivative of this model's LML: K ignores the parameter
     l0 = m.log_likelihood()
-    m.kern.lengthscale[:] = float(c.lengthscale[0]) * 1.5
+    m.kern.lengthscale[:] = np.asarray(c.lengthscale) * 1.5
     assert abs(m.log_likelihood() - l0) <= 1e-9 * abs(l0) and np.max(np.abs(dl0)) > 0
-    m.kern.lengthscale[:] = float(c.lengthscale[0])
+    m.kern.lengthscale[:] = np.asarray(c.lengthscale)
     # the host's default: the LML's TRUE gradient from the same device call (D x the fork's variance entry, 0 for the
     # lengthscale) == forward differences of the device LML, and the model's own checkgrad passes with it
     assert m.gower_gradients == 'exact'

@@ -86,15 +86,15 @@ def _gower():
     return g, dom, sorted({k.split("/")[0] for k in g.files if k.startswith("G_")})
 
 
-@pytest.mark.parametrize("tag", [t for t in _gower()[2] if "_N64_" in t or "_N150_" in t])
+@pytest.mark.parametrize("tag", [t for t in _gower()[2] if "_N64_" in t or "_N150_" in t or "_N100_" in t])
 def test_oracle_matches_gower_golden(tag):
     """The Gower fixture (made through the reference's verbatim Design_space and leaf modules) from the oracle alone:
     posterior, the fork's predictive gradients, estimate_L under the fixture's seed, the run.py:1234-1258 rows."""
     g, dom, _ = _gower()
     c = Case(g, tag)
     space = O.MixedSpace(dom)
-    kern = O.make_kernel("rbf" if int(c.kernel) == 0 else "Mat52", 6, float(c.variance), c.lengthscale, Gower=True,
-                         space=space)
+    kern = O.make_kernel("rbf" if int(c.kernel) == 0 else "Mat52", 6, float(c.variance), c.lengthscale,
+                         ARD=bool(int(c.ard)), Gower=True, space=space)
     gp = O.OracleGP(c.X, c.Y, kern, float(c.noise))
     assert np.array_equal(gp.posterior["K"][c.rows], c.K_rows)
     assert gp.posterior["lml"] == float(c.lml)

@@ -504,6 +504,8 @@ def main():
     with_c4 = args.workload == "auto" and world > 1 and not args.no_c4_section
     if world > 1:
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL's log lines belong on stderr: stdout carries the ONE JSON line
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the host driver's only mode): set before HIP loads,
+                                                                  # whoever launched this rank
         # A rank stuck inside a collective (a peer that never arrives, an RCCL bootstrap that finds no route) cannot be reached by a
         # Python-level handler while it sits in C: the default action of SIGALRM ends the process, whatever launched it.
         signal.signal(signal.SIGALRM, signal.SIG_DFL)

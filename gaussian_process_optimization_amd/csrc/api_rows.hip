@@ -121,7 +121,7 @@ static int rows_fused(gp_ctx *g, const double *Xs, int M, int include_noise, int
         launch_rows(g->s, g->dLi, g->Npad, rx, g->kp, g->dX, g->N, g->dAlpha, want_grad, g->kp.variance,
                     include_noise ? g->noise : 0.0, aq, w, g->hRowsOut, g->rows_nt < 0 ? (g->Npad > 8192 ? 1 : 0) : g->rows_nt);
         if (timed) phase_end(g, ph);
-        if ((rc = rows_wait(g, w, (unsigned)((g->N + 63) / 64)))) return rc;
+        if ((rc = rows_wait(g, w, rows_finish_grid(g->N)))) return rc;
         const double *o = g->hRowsOut;
         for (int m = 0; m < mc; ++m) {
             if (mean) mean[m0 + m] = o[m];
@@ -165,7 +165,7 @@ extern "C" int gp_predict_rows(gp_t *g, const double *Xs, int64_t M, int include
                     w.counter_base = g->rows_counter_base;
                 }
                 launch_rows_mean_grad(g->s, rx, g->kp, g->dX, g->N, g->dAlpha, w, g->hRowsOut);
-                if ((rc = rows_wait(g, w, (unsigned)((g->N + 255) / 256)))) return rc;
+                if ((rc = rows_wait(g, w, rows_mean_grad_grid(g->N)))) return rc;
                 memcpy(dmdx + (long)m0 * g->D, g->hRowsOut + 3 * MV, sizeof(double) * mc * g->D);
             }
             ++g->rows_fused_calls;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -212,6 +213,10 @@ struct RowsWork {             // device scratch (api_rows.hip sizes it): every p
 long rows_tiles(int nt);
 int rows_block_height(int nt);   // rows of the tile per workgroup: 32 for matrices of a few tiles, else 128
 size_t rows_gpart_elems(long N);
+// Workgroups of the pass's last launch -- the arrivals its counter waits for; the host adds the same number to the counter's base
+// after every pass (api_rows.hip rows_wait), so launcher and host take it from here.
+inline unsigned rows_finish_grid(long N) { return (unsigned)((N + 63) / 64); }       // rows_finish_kernel: 64 training rows per workgroup
+inline unsigned rows_mean_grad_grid(long N) { return (unsigned)((N + 255) / 256); }  // rows_mean_grad_kernel: one row per thread
 // results (host-visible block of 3 MV (1 + D) doubles, MV = 1 for M = 1 else ROWS_MAX_M):
 //   [mean MV][var MV][acq MV][dmdx MV D][dvdx MV D][dacq MV D]
 void launch_rows(hipStream_t s, const double *Li, long Npad, const RowsX &rx, const KernParams &kp, const double *X, long N,

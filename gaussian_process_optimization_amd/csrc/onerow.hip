@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void rows_mean_grad_kernel(RowsX rx, KernParam
 
 void launch_rows_mean_grad(hipStream_t s, const RowsX &rx, const KernParams &kp, const double *X, long N, const double *alpha,
                            const RowsWork &w, double *out) {
-    const unsigned grid = (unsigned)((N + 255) / 256);
+    const unsigned grid = rows_mean_grad_grid(N);
     if (rx.M == 1)
         GP_LAUNCH(rows_mean_grad_kernel<1>, dim3(grid), dim3(256), 0, s, rx, kp, X, N, alpha, w.gpart, w.counter, w.counter_base, out, w.ticket);
     else
@@ -448,7 +448,7 @@ void launch_rows_mean_grad(hipStream_t s, const RowsX &rx, const KernParams &kp,
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------------------------
-size_t rows_gpart_elems(long N) { return (size_t)((N + 63) / 64) * RW_GROW; }
+size_t rows_gpart_elems(long N) { return (size_t)std::max(rows_finish_grid(N), rows_mean_grad_grid(N)) * RW_GROW; }
 
 int rows_block_height(int nt) { return nt <= 16 ? 32 : GP_TILE; }
 
@@ -458,7 +458,7 @@ static void launch_rows_t(hipStream_t s, const double *Li, long Npad, const Rows
                           double *out) {
     const int nt = (int)(Npad / GP_TILE);
     const unsigned tiles = (unsigned)rows_tiles(nt) * (GP_TILE / RB);
-    const unsigned fin = (unsigned)((N + 63) / 64);
+    const unsigned fin = rows_finish_grid(N);
     GP_LAUNCH((rows_forward_kernel<MV, RB, NT>), dim3(tiles), dim3(256), 0, s, Li, Npad, rx, kp, X, N, alpha, w.wpart, Npad, nt, w.meanpart);
     if (want_grad)
         GP_LAUNCH((rows_backward_kernel<MV, RB, NT>), dim3(tiles), dim3(256), 0, s, Li, Npad, w.wpart, Npad, rx.M, w.bpart, w.vpart);
